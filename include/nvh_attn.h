@@ -1,0 +1,132 @@
+/*
+ * nvh_attn.h — C ABI of the MI355X (gfx950) paged-attention backend for nano-vllm.
+ *
+ * This is the drop-in boundary for `--attn-backend hip`: the entry points below are exactly
+ * what a reference-side binding (ctypes) calls from
+ * nanovllm/layers/attention.py's `Attention.forward`.  Plain C, raw device pointers and sizes,
+ * no torch / pybind types.  One process per GPU, single caller thread per process.
+ *
+ * Contract:
+ *   - The caller owns ALL memory, including the decode workspace.  The library allocates nothing,
+ *     frees nothing and keeps no state besides a thread-local error string.
+ *   - Every call only enqueues kernels on `stream` (a hipStream_t; NULL = default stream).  No host
+ *     synchronisation, no host reads of device data, grid sizes are functions of the static
+ *     arguments only -> every call is legal inside HIP-graph capture
+ *     (nanovllm/engine/model_runner.py:316-370 captures the decode forward).
+ *   - Return 0 on success; a negative NVH_E_* code for rejected arguments; a positive hipError_t
+ *     for a failed launch.  nvh_last_error() gives the message.  Nothing throws across the ABI.
+ *   - K/V cache layout is the reference's: [num_blocks, block_size, num_kv_heads, head_dim],
+ *     contiguous (model_runner.py:144-145, asserts attention.py:51-54).  All cache offsets are
+ *     64-bit inside the kernels.
+ *   - Element type of q/k/v/caches: bf16 (NVH_BF16), the reference's runtime dtype
+ *     (model_runner.py:35).  Outputs are bf16, or fp32 (NVH_F32) for pre-rounding parity checks.
+ *   - softmax scale is passed explicitly and must be head_dim**-0.5 to match the reference's
+ *     flash / sdpa backends (attention.py:96,101).
+ */
+#ifndef NVH_ATTN_H
+#define NVH_ATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVH_VERSION 100          /* major*100 + minor */
+
+/* dtype codes */
+#define NVH_BF16 0
+#define NVH_F32  1
+
+/* argument errors (negative so they never collide with hipError_t) */
+#define NVH_E_DTYPE      (-1)    /* unsupported element type */
+#define NVH_E_SHAPE      (-2)    /* unsupported head_dim / group size / block_size */
+#define NVH_E_STRIDE     (-3)    /* stride not a multiple of 8 elements (16-byte vector access) */
+#define NVH_E_WORKSPACE  (-4)    /* workspace too small */
+#define NVH_E_NULL       (-5)    /* required pointer is NULL */
+#define NVH_E_ALIGN      (-6)    /* pointer not 16-byte aligned */
+
+int nvh_version(void);
+const char* nvh_last_error(void);
+
+/*
+ * Scatter new K/V rows into the paged cache.
+ * Replaces: store_kvcache + store_kvcache_kernel, nanovllm/layers/attention.py:19-55
+ *           (slot < 0 rows are skipped, as nanovllm/layers/attention_triton.py:29-31 does for -1).
+ *   k, v           [n_tokens, kvh, hd]; inner two dims contiguous, row strides in ELEMENTS
+ *                  (v is a strided view of the fused qkv projection, models/qwen3.py:104-106)
+ *   k_cache/v_cache [num_blocks, block_size, kvh, hd] contiguous; row `slot` = slot*kvh*hd elements
+ *   slot_mapping   int32 [n_tokens], slot = block_id*block_size + offset (model_runner.py:212-221,254-258)
+ * n_tokens == 0 is a no-op.
+ */
+int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache,
+                      const int32_t* slot_mapping, int n_tokens, int kvh, int hd,
+                      int64_t k_row_stride, int64_t v_row_stride, int dtype, void* stream);
+
+/*
+ * Bytes of caller-owned scratch nvh_paged_decode needs (split-KV partials); a pure function of the
+ * static shapes so it can be allocated once before graph capture.
+ */
+size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int block_size);
+
+/*
+ * Decode: one query token per sequence attends its whole paged context.
+ * Replaces: flash_attn_with_kvcache(q.unsqueeze(1), k_cache, v_cache, cache_seqlens=context_lens,
+ *           block_table=block_tables, softmax_scale, causal=True), nanovllm/layers/attention.py:99-101
+ *           (oracle body nanovllm/layers/attention_sdpa.py:122-182).
+ *   out            [batch, h, hd]  (out_dtype NVH_BF16 or NVH_F32), contiguous
+ *   q              [batch, h, hd], contiguous per row; q_row_stride in elements
+ *   block_tables   int32 [batch, max_blocks], row stride bt_row_stride (elements); entries at or past
+ *                  ceil(ctx/block_size) are never dereferenced (they are -1 in eager mode and 0 under
+ *                  graph replay, model_runner.py:160-169,299)
+ *   context_lens   int32 [batch]; 0 -> the row's output is zeros (graph padding rows)
+ *   h % kvh == 0, h/kvh <= 8 per pass (larger groups are processed in passes), hd in {64, 128},
+ *   block_size a multiple of 64.
+ */
+int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                     const int32_t* block_tables, const int32_t* context_lens,
+                     int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                     int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                     int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Fused decode step for one layer: store this step's K/V row of every sequence, then attend.
+ * Replaces the pair of calls at nanovllm/layers/attention.py:84-86 and :99-101 with one launch
+ * sequence; result identical to nvh_store_kvcache followed by nvh_paged_decode.
+ *   k_new, v_new   [batch, kvh, hd] with row strides in elements; slot_mapping int32 [batch]
+ */
+int nvh_decode_step(void* out, const void* q, const void* k_new, const void* v_new,
+                    void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                    const int32_t* block_tables, const int32_t* context_lens,
+                    int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                    int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                    int64_t bt_row_stride, float scale, int dtype, int out_dtype,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * Prefill: packed variable-length causal attention.
+ * Replaces: flash_attn_varlen_func(q, k, v, cu_seqlens_q/k, max_seqlen_q/k, softmax_scale,
+ *           causal=True, block_table=...), nanovllm/layers/attention.py:93-96
+ *           (oracle body nanovllm/layers/attention_sdpa.py:65-119).
+ *   block_tables == NULL : k, v are the new tokens [total_k, kvh, hd] with row strides (elements).
+ *   block_tables != NULL : k, v are the paged caches (prefix-cache prefill, attention.py:90-91);
+ *                          k/v_row_stride are ignored; sequence i's keys are found through
+ *                          block_tables[i, :]; block_size/max_blocks/bt_row_stride describe it.
+ *   cu_seqlens_q/k int32 [batch+1] on device; max_seqlen_q bounds the launch grid (host int, as in
+ *                  model_runner.py:204-207).  The causal mask is bottom-right aligned: query row r
+ *                  of a sequence sees keys 0 .. r + (Sk - Sq)  (flash-attn semantics; equals the
+ *                  oracle's top-left mask whenever Sq == Sk).
+ *   out            [total_q, h, hd] contiguous, out_dtype NVH_BF16 or NVH_F32.
+ */
+int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
+                       const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                       const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
+                       int h, int kvh, int hd, int block_size, int max_blocks,
+                       int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                       int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVH_ATTN_H */

@@ -1,0 +1,204 @@
+// C ABI of libnvh_attn.so (declared in include/nvh_attn.h): argument validation mirroring the
+// reference's asserts (nanovllm/layers/attention.py:51-54), error strings, kernel dispatch.
+// Nothing here allocates, synchronises or reads device memory: every entry point is capture-safe.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "../../include/nvh_attn.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace nvh {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int check_heads(const char* fn, int h, int kvh, int hd) {
+    if (hd != 64 && hd != 128) {
+        set_error("%s: head_dim %d unsupported (64 or 128)", fn, hd);
+        return NVH_E_SHAPE;
+    }
+    if (h <= 0 || kvh <= 0 || h % kvh != 0) {
+        set_error("%s: num_heads %d must be a positive multiple of num_kv_heads %d", fn, h, kvh);
+        return NVH_E_SHAPE;
+    }
+    return 0;
+}
+
+}  // namespace nvh
+
+using namespace nvh;
+
+extern "C" {
+
+int nvh_version(void) { return NVH_VERSION; }
+
+const char* nvh_last_error(void) { return g_err; }
+
+int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache,
+                      const int32_t* slot_mapping, int n_tokens, int kvh, int hd,
+                      int64_t k_row_stride, int64_t v_row_stride, int dtype, void* stream) {
+    if (n_tokens == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("store_kvcache: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!k || !v || !k_cache || !v_cache || !slot_mapping) { set_error("store_kvcache: null pointer"); return NVH_E_NULL; }
+    if (n_tokens < 0 || kvh <= 0 || hd <= 0 || (kvh * hd) % 8 != 0) {
+        set_error("store_kvcache: kvh*hd = %d*%d must be a positive multiple of 8", kvh, hd);
+        return NVH_E_SHAPE;
+    }
+    // reference asserts: inner dims contiguous (attention.py:51-52), cache rows = kvh*hd (:53)
+    if (k_row_stride % 8 || v_row_stride % 8 || k_row_stride < (int64_t)kvh * hd || v_row_stride < (int64_t)kvh * hd) {
+        set_error("store_kvcache: row strides %lld/%lld must be multiples of 8 and >= kvh*hd",
+                  (long long)k_row_stride, (long long)v_row_stride);
+        return NVH_E_STRIDE;
+    }
+    if (!aligned16(k) || !aligned16(v) || !aligned16(k_cache) || !aligned16(v_cache)) {
+        set_error("store_kvcache: pointers must be 16-byte aligned");
+        return NVH_E_ALIGN;
+    }
+    return launch_store_kvcache(k, v, k_cache, v_cache, slot_mapping, n_tokens, kvh, hd,
+                                k_row_stride, v_row_stride, (hipStream_t)stream);
+}
+
+static int decode_num_splits(int hd, int max_blocks, int block_size) {
+    const int split = decode_split_tokens(hd);
+    const int64_t cap = (int64_t)max_blocks * block_size;
+    int n = (int)((cap + split - 1) / split);
+    return n < 1 ? 1 : n;
+}
+
+size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int block_size) {
+    if (batch <= 0 || h <= 0 || (hd != 64 && hd != 128) || max_blocks <= 0 || block_size <= 0) return 0;
+    const size_t parts = (size_t)batch * h * decode_num_splits(hd, max_blocks, block_size);
+    return parts * (size_t)(hd + 2) * sizeof(float);
+}
+
+int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                     const int32_t* block_tables, const int32_t* context_lens,
+                     int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                     int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                     int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (batch == 0) return 0;
+    if (dtype != NVH_BF16 || (out_dtype != NVH_BF16 && out_dtype != NVH_F32)) {
+        set_error("paged_decode: dtype %d / out_dtype %d unsupported", dtype, out_dtype);
+        return NVH_E_DTYPE;
+    }
+    if (!out || !q || !k_cache || !v_cache || !block_tables || !context_lens || !workspace) {
+        set_error("paged_decode: null pointer");
+        return NVH_E_NULL;
+    }
+    int rc = check_heads("paged_decode", h, kvh, hd);
+    if (rc) return rc;
+    if (h / kvh > 8) { set_error("paged_decode: group size %d > 8 unsupported", h / kvh); return NVH_E_SHAPE; }
+    if (batch < 0 || max_blocks <= 0 || block_size <= 0 || block_size % 64 != 0) {
+        set_error("paged_decode: block_size %d must be a positive multiple of 64, max_blocks %d > 0", block_size, max_blocks);
+        return NVH_E_SHAPE;
+    }
+    if (q_row_stride % 8 || q_row_stride < (int64_t)h * hd || bt_row_stride < max_blocks) {
+        set_error("paged_decode: bad strides q=%lld bt=%lld", (long long)q_row_stride, (long long)bt_row_stride);
+        return NVH_E_STRIDE;
+    }
+    if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(workspace) || !aligned16(out)) {
+        set_error("paged_decode: pointers must be 16-byte aligned");
+        return NVH_E_ALIGN;
+    }
+    const size_t need = nvh_paged_decode_workspace(batch, h, hd, max_blocks, block_size);
+    if (workspace_bytes < need) {
+        set_error("paged_decode: workspace %zu B < required %zu B", workspace_bytes, need);
+        return NVH_E_WORKSPACE;
+    }
+    DecodeArgs a;
+    a.out = out;
+    a.q = (const uint16_t*)q;
+    a.k_cache = (const uint16_t*)k_cache;
+    a.v_cache = (const uint16_t*)v_cache;
+    a.block_tables = block_tables;
+    a.context_lens = context_lens;
+    a.batch = batch; a.h = h; a.kvh = kvh; a.hd = hd;
+    a.block_size = block_size; a.max_blocks = max_blocks;
+    a.num_splits = decode_num_splits(hd, max_blocks, block_size);
+    a.ws_acc = (float*)workspace;
+    a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;
+    a.q_row_stride = q_row_stride; a.bt_row_stride = bt_row_stride;
+    a.scale_log2 = scale * kLog2e;
+    a.out_f32 = out_dtype == NVH_F32;
+    return launch_paged_decode(a, (hipStream_t)stream);
+}
+
+int nvh_decode_step(void* out, const void* q, const void* k_new, const void* v_new,
+                    void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                    const int32_t* block_tables, const int32_t* context_lens,
+                    int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                    int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                    int64_t bt_row_stride, float scale, int dtype, int out_dtype,
+                    void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = nvh_store_kvcache(k_new, v_new, k_cache, v_cache, slot_mapping, batch, kvh, hd,
+                               k_row_stride, v_row_stride, dtype, stream);
+    if (rc) return rc;
+    return nvh_paged_decode(out, q, k_cache, v_cache, block_tables, context_lens, batch, h, kvh, hd,
+                            block_size, max_blocks, q_row_stride, bt_row_stride, scale, dtype, out_dtype,
+                            workspace, workspace_bytes, stream);
+}
+
+int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
+                       const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                       const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
+                       int h, int kvh, int hd, int block_size, int max_blocks,
+                       int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                       int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream) {
+    if (batch == 0 || max_seqlen_q == 0) return 0;
+    if (dtype != NVH_BF16 || (out_dtype != NVH_BF16 && out_dtype != NVH_F32)) {
+        set_error("prefill_varlen: dtype %d / out_dtype %d unsupported", dtype, out_dtype);
+        return NVH_E_DTYPE;
+    }
+    if (!out || !q || !k || !v || !cu_seqlens_q || !cu_seqlens_k) { set_error("prefill_varlen: null pointer"); return NVH_E_NULL; }
+    int rc = check_heads("prefill_varlen", h, kvh, hd);
+    if (rc) return rc;
+    if (batch < 0 || max_seqlen_q < 0 || max_seqlen_k < 0) { set_error("prefill_varlen: negative size"); return NVH_E_SHAPE; }
+    if (q_row_stride % 8 || q_row_stride < (int64_t)h * hd) {
+        set_error("prefill_varlen: q row stride %lld", (long long)q_row_stride);
+        return NVH_E_STRIDE;
+    }
+    if (block_tables) {
+        if (block_size <= 0 || max_blocks <= 0 || bt_row_stride < max_blocks) {
+            set_error("prefill_varlen: paged mode needs block_size/max_blocks/bt_row_stride");
+            return NVH_E_SHAPE;
+        }
+    } else if (k_row_stride % 8 || v_row_stride % 8 || k_row_stride < (int64_t)kvh * hd || v_row_stride < (int64_t)kvh * hd) {
+        set_error("prefill_varlen: k/v row strides %lld/%lld", (long long)k_row_stride, (long long)v_row_stride);
+        return NVH_E_STRIDE;
+    }
+    if (!aligned16(q) || !aligned16(k) || !aligned16(v) || !aligned16(out)) {
+        set_error("prefill_varlen: pointers must be 16-byte aligned");
+        return NVH_E_ALIGN;
+    }
+    PrefillArgs a;
+    a.out = out;
+    a.q = (const uint16_t*)q; a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
+    a.cu_q = cu_seqlens_q; a.cu_k = cu_seqlens_k; a.block_tables = block_tables;
+    a.batch = batch; a.max_seqlen_q = max_seqlen_q; a.max_seqlen_k = max_seqlen_k;
+    a.h = h; a.kvh = kvh; a.hd = hd; a.block_size = block_size; a.max_blocks = max_blocks;
+    a.q_row_stride = q_row_stride; a.k_row_stride = k_row_stride; a.v_row_stride = v_row_stride;
+    a.bt_row_stride = bt_row_stride;
+    a.scale_log2 = scale * kLog2e;
+    a.out_f32 = out_dtype == NVH_F32;
+    return launch_prefill_varlen(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

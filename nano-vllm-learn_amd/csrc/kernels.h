@@ -1,0 +1,47 @@
+// Internal launcher interface between api.hip (argument validation, C ABI) and the kernel files.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace nvh {
+
+int launch_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache,
+                         const int32_t* slot_mapping, int n_tokens, int kvh, int hd,
+                         int64_t k_row_stride, int64_t v_row_stride, hipStream_t stream);
+
+struct DecodeArgs {
+    void* out;                   // [B, H, D] bf16 or f32
+    const uint16_t* q;           // [B, H, D] bf16, row stride q_row_stride
+    const uint16_t* k_cache;     // [NB, bs, KVH, D]
+    const uint16_t* v_cache;
+    const int32_t* block_tables; // [B, max_blocks], row stride bt_row_stride
+    const int32_t* context_lens; // [B]
+    float* ws_acc;               // [B, H, num_splits, D] un-normalised partial outputs
+    float* ws_ml;                // [B, H, num_splits, 2]  (running max in log2 domain, sum)
+    int batch, h, kvh, hd, block_size, max_blocks, num_splits;
+    int64_t q_row_stride, bt_row_stride;
+    float scale_log2;            // softmax scale * log2(e)
+    int out_f32;
+};
+
+// tokens one workgroup of the split kernel covers (static function of head_dim)
+int decode_split_tokens(int hd);
+int launch_paged_decode(const DecodeArgs& a, hipStream_t stream);
+
+struct PrefillArgs {
+    void* out;                   // [Tq, H, D]
+    const uint16_t* q;           // [Tq, H, D], row stride q_row_stride
+    const uint16_t* k;           // [Tk, KVH, D] rows (k_row_stride) or paged cache when block_tables != null
+    const uint16_t* v;
+    const int32_t* cu_q;         // [B+1]
+    const int32_t* cu_k;         // [B+1]
+    const int32_t* block_tables; // nullable
+    int batch, max_seqlen_q, max_seqlen_k, h, kvh, hd, block_size, max_blocks;
+    int64_t q_row_stride, k_row_stride, v_row_stride, bt_row_stride;
+    float scale_log2;
+    int out_f32;
+};
+int launch_prefill_varlen(const PrefillArgs& a, hipStream_t stream);
+
+}  // namespace nvh

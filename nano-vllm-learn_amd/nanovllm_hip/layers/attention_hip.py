@@ -1,0 +1,58 @@
+"""`--attn-backend hip`: the MI355X attention module, a drop-in beside the reference's flash / sdpa /
+triton `Attention` classes (nanovllm/layers/attention.py:58-103, attention_sdpa.py:208-269,
+attention_triton.py:386-464).
+
+Same constructor `(num_heads, head_dim, scale, num_kv_heads, **kw)`, same `k_cache` / `v_cache`
+attributes (the runner binds cache views by `hasattr`, engine/model_runner.py:148-157), same
+`forward(q, k, v) -> o` on flattened `[N, H*D]` / `[N, KVH*D]` tensors, same global Context.
+All arithmetic happens in libnvh_attn.so; there is no eager / CPU fallback.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..utils.context import get_context
+
+
+class Attention(nn.Module):
+
+    def __init__(self, num_heads, head_dim, scale, num_kv_heads, block_size: int = 256, fused_decode: bool = True):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = head_dim
+        self.scale = scale                      # softmax scale, D**-0.5 (models/qwen3.py:40); used as given
+        self.num_kv_heads = num_kv_heads
+        self.block_size = block_size
+        self.fused_decode = fused_decode        # one C-ABI call for store + attend on the decode step
+        self.k_cache = self.v_cache = torch.tensor([])
+
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
+        q = q.view(-1, self.num_heads, self.head_dim)
+        k = k.view(-1, self.num_kv_heads, self.head_dim)
+        v = v.view(-1, self.num_kv_heads, self.head_dim)
+        context = get_context()
+        k_cache, v_cache = self.k_cache, self.v_cache
+        have_cache = k_cache.numel() > 0 and v_cache.numel() > 0       # warmup prefill runs before allocation
+        store = have_cache and context.slot_mapping is not None        # attention.py:84, attention_sdpa.py:242
+
+        if context.is_prefill:
+            if store:
+                ops.store_kvcache(k, v, k_cache, v_cache, context.slot_mapping)
+            if context.block_tables is not None:                        # prefix-cache hit: read K/V from the cache
+                k, v = k_cache, v_cache
+            o = ops.flash_attn_varlen_func(q, k, v,
+                                           max_seqlen_q=context.max_seqlen_q, cu_seqlens_q=context.cu_seqlens_q,
+                                           max_seqlen_k=context.max_seqlen_k, cu_seqlens_k=context.cu_seqlens_k,
+                                           softmax_scale=self.scale, causal=True, block_table=context.block_tables)
+        else:
+            if not have_cache:
+                raise RuntimeError("decode needs an allocated KV cache (k_cache/v_cache not bound)")
+            if store and self.fused_decode:
+                o = ops.decode_step(q, k, v, k_cache, v_cache, context.slot_mapping, context.context_lens,
+                                    context.block_tables, softmax_scale=self.scale)
+            else:
+                if store:
+                    ops.store_kvcache(k, v, k_cache, v_cache, context.slot_mapping)
+                o = ops.flash_attn_with_kvcache(q.unsqueeze(1), k_cache, v_cache, cache_seqlens=context.context_lens,
+                                                block_table=context.block_tables, softmax_scale=self.scale, causal=True)
+        return o.view(-1, self.num_heads * self.head_dim)

@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the C ABI (include/nvh_attn.h).
+
+Same function names and argument meaning as the helpers the reference's attention modules call
+(store_kvcache: nanovllm/layers/attention.py:44-55; flash_attn_with_kvcache / flash_attn_varlen_func:
+call sites attention.py:93-101, oracle bodies nanovllm/layers/attention_sdpa.py:65-182), so parity
+tests read like the reference.  Everything runs on torch's CURRENT stream and is graph-capture safe:
+no host synchronisation, no host reads of device data.  There is no fallback: tensors must live on
+a GPU and the HIP library must load.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import NVH_BF16, NVH_F32
+
+_workspaces: dict[int, torch.Tensor] = {}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _out_code(dtype):
+    if dtype == torch.bfloat16:
+        return NVH_BF16
+    if dtype == torch.float32:
+        return NVH_F32
+    raise TypeError(f"output dtype {dtype} unsupported (bfloat16 or float32)")
+
+
+def _require_gpu_bf16(**tensors):
+    for name, t in tensors.items():
+        if not t.is_cuda:
+            raise RuntimeError(f"{name} must be a GPU tensor: the hip attention backend has no CPU path")
+        if t.dtype != torch.bfloat16:
+            raise TypeError(f"{name} must be bfloat16 (the reference's runtime dtype), got {t.dtype}")
+
+
+def _require_i32(**tensors):
+    for name, t in tensors.items():
+        if not t.is_cuda or t.dtype != torch.int32:
+            raise TypeError(f"{name} must be an int32 GPU tensor, got {t.dtype} on {t.device}")
+
+
+# --------------------------------------------------------------------------------------- store
+def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                  slot_mapping: torch.Tensor) -> None:
+    """cache.view(-1, KVH*D)[slot_mapping[i]] = key[i] / value[i]; rows with slot < 0 are skipped.
+
+    key/value [N, KVH, D] with contiguous inner dims and any row stride (attention.py:49-55)."""
+    n, kvh, hd = key.shape
+    d = kvh * hd
+    _require_gpu_bf16(key=key, value=value, k_cache=k_cache, v_cache=v_cache)
+    _require_i32(slot_mapping=slot_mapping)
+    assert value.shape == key.shape
+    assert key.stride(-1) == 1 and value.stride(-1) == 1                 # attention.py:51
+    assert key.stride(1) == hd and value.stride(1) == hd                 # attention.py:52
+    assert k_cache.stride(1) == d and v_cache.stride(1) == d             # attention.py:53
+    assert k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert slot_mapping.numel() == n and slot_mapping.is_contiguous()    # attention.py:54
+    rc = _lib.load().nvh_store_kvcache(key.data_ptr(), value.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                       slot_mapping.data_ptr(), n, kvh, hd, key.stride(0), value.stride(0),
+                                       NVH_BF16, _stream())
+    _lib.check(rc, "nvh_store_kvcache")
+
+
+# --------------------------------------------------------------------------------------- decode
+def decode_workspace_bytes(batch, num_heads, head_dim, max_blocks, block_size) -> int:
+    return int(_lib.load().nvh_paged_decode_workspace(batch, num_heads, head_dim, max_blocks, block_size))
+
+
+def reserve_workspace(device, nbytes: int) -> torch.Tensor:
+    """Grow (never shrink) the per-device split-KV scratch.  Call before graph capture with the largest
+    shape; all layers share it (they run back to back on one stream, so it stays hot in L2)."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    ws = _workspaces.get(idx)
+    if ws is None or ws.numel() < nbytes:
+        if ws is not None and torch.cuda.is_current_stream_capturing():
+            return torch.empty(nbytes, dtype=torch.uint8, device=device)   # graph-pool memory, not cached
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if not torch.cuda.is_current_stream_capturing():
+            _workspaces[idx] = ws
+    return ws
+
+
+def _decode_common(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype):
+    squeeze = q.dim() == 4
+    if squeeze:
+        assert q.shape[1] == 1, "Decode stage should have seq_len=1"      # attention_sdpa.py:133
+        q3 = q[:, 0]
+    else:
+        q3 = q
+    b, h, hd = q3.shape
+    nb, bs, kvh, hd2 = k_cache.shape
+    assert hd2 == hd and v_cache.shape == k_cache.shape
+    _require_gpu_bf16(q=q, k_cache=k_cache, v_cache=v_cache)
+    _require_i32(cache_seqlens=cache_seqlens, block_table=block_table)
+    assert q3.stride(-1) == 1 and q3.stride(1) == hd
+    assert k_cache.is_contiguous() and v_cache.is_contiguous()
+    assert block_table.dim() == 2 and block_table.shape[0] == b and block_table.stride(1) == 1
+    assert cache_seqlens.numel() == b and cache_seqlens.is_contiguous()
+    if softmax_scale is None:
+        softmax_scale = hd ** -0.5
+    out_dtype = out_dtype or torch.bfloat16
+    if out is None:
+        out = torch.empty((b, h, hd), dtype=out_dtype, device=q.device)
+    else:
+        assert out.shape == (b, h, hd) and out.is_contiguous() and out.dtype == out_dtype
+    max_blocks = block_table.shape[1]
+    need = decode_workspace_bytes(b, h, hd, max_blocks, bs)
+    ws = reserve_workspace(q.device, need)
+    return squeeze, q3, b, h, hd, kvh, bs, max_blocks, float(softmax_scale), out, ws
+
+
+def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale=None, causal=True,
+                            out=None, out_dtype=None):
+    """Decode attention, drop-in for the call at attention.py:99-101.
+
+    q [B, 1, H, D] (or [B, H, D]); caches [NB, bs, KVH, D]; cache_seqlens int32 [B] (0 -> zero row);
+    block_table int32 [B, max_blocks].  `causal` is accepted for signature parity; with one query per
+    sequence it has no effect.  Returns [B, 1, H, D] (or [B, H, D])."""
+    squeeze, q3, b, h, hd, kvh, bs, max_blocks, scale, out, ws = _decode_common(
+        q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype)
+    rc = _lib.load().nvh_paged_decode(out.data_ptr(), q3.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+                                      block_table.data_ptr(), cache_seqlens.data_ptr(), b, h, kvh, hd, bs, max_blocks,
+                                      q3.stride(0), block_table.stride(0), scale, NVH_BF16, _out_code(out.dtype),
+                                      ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "nvh_paged_decode")
+    return out.unsqueeze(1) if squeeze else out
+
+
+def decode_step(q, k_new, v_new, k_cache, v_cache, slot_mapping, cache_seqlens, block_table, softmax_scale=None,
+                out=None, out_dtype=None):
+    """store_kvcache(k_new, v_new, ...) followed by flash_attn_with_kvcache(q, ...) as one C-ABI call
+    (the two calls at attention.py:84-86 and :99-101)."""
+    squeeze, q3, b, h, hd, kvh, bs, max_blocks, scale, out, ws = _decode_common(
+        q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype)
+    _require_gpu_bf16(k_new=k_new, v_new=v_new)
+    _require_i32(slot_mapping=slot_mapping)
+    assert k_new.shape == (b, kvh, hd) and v_new.shape == (b, kvh, hd)
+    assert k_new.stride(-1) == 1 and v_new.stride(-1) == 1 and k_new.stride(1) == hd and v_new.stride(1) == hd
+    assert slot_mapping.numel() == b and slot_mapping.is_contiguous()
+    rc = _lib.load().nvh_decode_step(out.data_ptr(), q3.data_ptr(), k_new.data_ptr(), v_new.data_ptr(),
+                                     k_cache.data_ptr(), v_cache.data_ptr(), slot_mapping.data_ptr(),
+                                     block_table.data_ptr(), cache_seqlens.data_ptr(), b, h, kvh, hd, bs, max_blocks,
+                                     q3.stride(0), k_new.stride(0), v_new.stride(0), block_table.stride(0), scale,
+                                     NVH_BF16, _out_code(out.dtype), ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "nvh_decode_step")
+    return out.unsqueeze(1) if squeeze else out
+
+
+# --------------------------------------------------------------------------------------- prefill
+def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu_seqlens_k, softmax_scale=None,
+                           causal=True, block_table=None, out_dtype=None):
+    """Packed varlen causal attention, drop-in for the call at attention.py:93-96.
+
+    q [Tq, H, D]; without block_table k/v are [Tk, KVH, D] (any row stride); with block_table they are
+    the paged caches [NB, bs, KVH, D] and sequence i reads its keys through block_table[i]."""
+    if not causal:
+        raise NotImplementedError("the reference only ever calls this with causal=True (attention.py:96)")
+    tq, h, hd = q.shape
+    _require_gpu_bf16(q=q, k=k, v=v)
+    _require_i32(cu_seqlens_q=cu_seqlens_q, cu_seqlens_k=cu_seqlens_k)
+    assert q.stride(-1) == 1 and q.stride(1) == hd
+    batch = cu_seqlens_q.numel() - 1
+    assert cu_seqlens_k.numel() == batch + 1
+    if softmax_scale is None:
+        softmax_scale = hd ** -0.5
+    out = torch.empty((tq, h, hd), dtype=out_dtype or torch.bfloat16, device=q.device)
+    if block_table is not None:
+        _require_i32(block_table=block_table)
+        nb, bs, kvh, hd2 = k.shape
+        assert hd2 == hd and v.shape == k.shape and k.is_contiguous() and v.is_contiguous()
+        assert block_table.shape[0] == batch and block_table.stride(1) == 1
+        max_blocks, bt_stride, bt_ptr = block_table.shape[1], block_table.stride(0), block_table.data_ptr()
+        k_stride = v_stride = kvh * hd
+    else:
+        tk, kvh, hd2 = k.shape
+        assert hd2 == hd and v.shape == k.shape
+        assert k.stride(-1) == 1 and v.stride(-1) == 1 and k.stride(1) == hd and v.stride(1) == hd
+        bs, max_blocks, bt_stride, bt_ptr = 0, 0, 0, None
+        k_stride, v_stride = k.stride(0), v.stride(0)
+    rc = _lib.load().nvh_prefill_varlen(out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
+                                        cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), bt_ptr, batch,
+                                        int(max_seqlen_q), int(max_seqlen_k), h, kvh, hd, bs, max_blocks,
+                                        q.stride(0), k_stride, v_stride, bt_stride, float(softmax_scale),
+                                        NVH_BF16, _out_code(out.dtype), _stream())
+    _lib.check(rc, "nvh_prefill_varlen")
+    return out
