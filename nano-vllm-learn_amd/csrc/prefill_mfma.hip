@@ -28,7 +28,7 @@ namespace nvh {
 namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 64;      // query rows per workgroup
 constexpr int BN = 32;      // keys per LDS tile
@@ -158,14 +158,9 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
             // lane 4q+p of its 16-lane group addresses key row (4*lg + q), dims 16t + 4p .. +3
             const int vq = lq >> 2, vp = lq & 3;
             const unsigned char* base = lds_v + (4 * lg + vq) * ROWB + (16 * t + 4 * vp) * 2;
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(base + 16 * ROWB));
-            bf16x8 vf;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vf[i] = __builtin_bit_cast(__bf16, lo[i]);
-                vf[4 + i] = __builtin_bit_cast(__bf16, hi[i]);
-            }
+            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base));
+            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base + 16 * ROWB));
+            const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // whole-register concat, no repack
             o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
         }
     }

@@ -9,7 +9,7 @@ for path in sorted(glob.glob(os.path.join(here, "build", "*.resources.txt"))):
         m = re.search(r"Function Name: (\S+)", line)
         if m:
             name = subprocess.run(["c++filt", m.group(1)], capture_output=True, text=True).stdout.strip()
-            cur = {"name": re.sub(r"\(.*", "", name).replace("nvh::(anonymous namespace)::", "").replace("void ", "")}
+            cur = {"name": re.sub(r"\(.*", "", name.replace("(anonymous namespace)::", "")).replace("void ", "").replace("nvh::", "")}
             rows.append(cur)
             continue
         for key in ("VGPRs", "AGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]", "SGPRs"):
