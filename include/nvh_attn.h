@@ -81,7 +81,7 @@ size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int 
  *                  ceil(ctx/block_size) are never dereferenced (they are -1 in eager mode and 0 under
  *                  graph replay, model_runner.py:160-169,299)
  *   context_lens   int32 [batch]; 0 -> the row's output is zeros (graph padding rows)
- *   h % kvh == 0, h/kvh <= 8 per pass (larger groups are processed in passes), hd in {64, 128},
+ *   h % kvh == 0, h/kvh <= 16, hd in {64, 128},
  *   block_size a multiple of 64.
  */
 int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* v_cache,

@@ -28,6 +28,9 @@ int check_launch(const char* what) {
     return 0;
 }
 
+// diagnostic builds (-DNVH_STAMPS) set this through nvh_debug_set_stamps; always null in the shipped library
+static unsigned long long* g_stamps = nullptr;
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 static int check_heads(const char* fn, int h, int kvh, int hd) {
@@ -49,6 +52,10 @@ using namespace nvh;
 extern "C" {
 
 int nvh_version(void) { return NVH_VERSION; }
+
+#ifdef NVH_STAMPS
+void nvh_debug_set_stamps(void* p) { g_stamps = (unsigned long long*)p; }
+#endif
 
 const char* nvh_last_error(void) { return g_err; }
 
@@ -105,7 +112,7 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
     }
     int rc = check_heads("paged_decode", h, kvh, hd);
     if (rc) return rc;
-    if (h / kvh > 8) { set_error("paged_decode: group size %d > 8 unsupported", h / kvh); return NVH_E_SHAPE; }
+    if (h / kvh > 16) { set_error("paged_decode: group size %d > 16 unsupported", h / kvh); return NVH_E_SHAPE; }
     if (batch < 0 || max_blocks <= 0 || block_size <= 0 || block_size % 64 != 0) {
         set_error("paged_decode: block_size %d must be a positive multiple of 64, max_blocks %d > 0", block_size, max_blocks);
         return NVH_E_SHAPE;
@@ -138,6 +145,7 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
     a.q_row_stride = q_row_stride; a.bt_row_stride = bt_row_stride;
     a.scale_log2 = scale * kLog2e;
     a.out_f32 = out_dtype == NVH_F32;
+    a.stamps = g_stamps;
     return launch_paged_decode(a, (hipStream_t)stream);
 }
 

@@ -52,8 +52,33 @@ __device__ __forceinline__ float pair_in_row(float x) {
     else return dpp_f32<0x128>(x);                              // row_ror:8
 }
 
-__device__ __forceinline__ float xor16(float x) { return __shfl_xor(x, 16, 64); }
-__device__ __forceinline__ float xor32(float x) { return __shfl_xor(x, 32, 64); }
+// ---- cross-row exchanges (gfx950 v_permlane16_swap / v_permlane32_swap) -----------------------------------
+// v_permlane32_swap vdst, src : lanes 32..63 of vdst <-> lanes 0..31 of src.
+// v_permlane16_swap vdst, src : odd 16-lane rows of vdst <-> even rows of src.
+// With vdst == src == x both halves of every pair end up in the two results, so a symmetric
+// reduction of the two results is an all-reduce over the pair (rows r, r^1 / lanes l, l^32).
+__device__ __forceinline__ float max_xor16(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// Reduce-scatter steps: ONE swap + ONE add folds TWO values over the pair.
+//   fold32(a, b): lanes 0..31 get a[l] + a[l+32], lanes 32..63 get b[l-32] + b[l].
+//   fold16(a, b): even rows get a summed over (row, row+1), odd rows get b summed over (row-1, row).
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float sum_xor16(float x) { return fold16(x, x); }
+__device__ __forceinline__ float sum_xor32(float x) { return fold32(x, x); }
 
 // all-reduce (sum) over the LANES lanes that share lane/LANES; LANES in {8,16}
 template <int LANES>
@@ -65,19 +90,12 @@ __device__ __forceinline__ float group_sum(float x) {
     return x;
 }
 
-// all-reduce over the lanes that share lane%LANES (the 64/LANES token slots of a wave); LANES in {8,16}
-template <int LANES>
-__device__ __forceinline__ float slot_sum(float x) {
-    if constexpr (LANES == 8) x += pair_in_row<8>(x);
-    x += xor16(x);
-    x += xor32(x);
-    return x;
-}
+// all-reduce (max) over the lanes that share lane%LANES (the 64/LANES token slots of a wave); LANES in {8,16}
 template <int LANES>
 __device__ __forceinline__ float slot_max(float x) {
     if constexpr (LANES == 8) x = fmaxf(x, pair_in_row<8>(x));
-    x = fmaxf(x, xor16(x));
-    x = fmaxf(x, xor32(x));
+    x = max_xor16(x);
+    x = max_xor32(x);
     return x;
 }
 

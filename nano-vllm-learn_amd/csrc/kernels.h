@@ -23,6 +23,7 @@ struct DecodeArgs {
     int64_t q_row_stride, bt_row_stride;
     float scale_log2;            // softmax scale * log2(e)
     int out_f32;
+    unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
 };
 
 // tokens one workgroup of the split kernel covers (static function of head_dim)

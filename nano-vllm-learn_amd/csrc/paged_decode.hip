@@ -7,27 +7,29 @@
 //     sum_b 2*ctx_b*KVH*D*2  +  2*B*H*D*2 (q in, o out)  +  4*(sum_b ceil(ctx_b/bs) + B)
 // Split-KV partials and the combine pass are overhead, not algorithmic.
 //
-// Structure (flash-decoding, wave64, no MFMA: M = G <= 8 rows is not a dense contraction):
-//   split kernel   grid (num_splits, KVH, B), 256 threads = 4 waves.  A workgroup owns 256 consecutive
-//                  tokens of one (sequence, kv head); each wave owns a tile of 64 of them and issues ALL
-//                  its loads up front (K: 8 or 16 KiB by LDS-DMA, V: the same again into VGPRs).
-//     K path       global_load_lds_dwordx4 (HBM -> LDS, no VGPRs): one instruction = 1 KiB = 64/LPT whole
-//                  token rows, fully coalesced.  The LDS image is row-major [64 tokens][D bf16]; the
-//                  16-byte chunk order inside a row is XOR-swizzled on the SOURCE address so that the
-//                  per-token row reads below are bank-conflict free.
-//     QK^T         lane = token.  Each lane reads its own K row from LDS chunk by chunk (ds_read_b128) and
-//                  the group's q chunks as LDS broadcasts; v_dot2c_f32_bf16 accumulates in fp32.  No
-//                  cross-lane reduction, one exp2 per (token, head).
-//     softmax      tile max per head by a wavefront reduction (DPP inside 16-lane rows, permlane swaps
-//                  across rows); p = 2^(s - m) goes to an LDS tile [token][head].
-//     PV           lane = (token slot, 16-byte dim chunk): V rows are still in the registers the coalesced
-//                  loads filled; p is an LDS broadcast read; acc[G][8] fp32 FMAs per lane.
-//     epilogue     token slots folded by DPP + LDS, the 4 waves merged with their own maxima, one
-//                  (max, sum, acc[G][D]) partial per workgroup written to the workspace.
-//   combine kernel one thread per output element: loads every live partial in one round trip, merges,
-//                  normalises, rounds to bf16 (or fp32 for parity checks).
+// Structure (flash-decoding, wave64, VALU only: M = G <= 8 query rows is not a dense contraction):
+//   split kernel   grid (num_splits, KVH, B), 512 threads = 8 waves; a workgroup owns SPLIT consecutive
+//                  tokens of one (sequence, kv head), each wave a tile of WT = SPLIT/8 of them.
+//     loads        a token row (D bf16) is read by LPT = D/8 lanes x 16 B, so one global_load_dwordx4 wave
+//                  instruction moves 1 KiB = TPI = 64/LPT whole rows, fully coalesced.  A wave issues its
+//                  NI K loads and NI V loads back to back (8 KiB in flight per wave, ~3 waves per SIMD) and
+//                  the compiler's counted vmcnt waits let it start on token slot 0 as soon as that load
+//                  lands.  K/V go straight to VGPRs: read once, no reuse, so no LDS staging (measured: the
+//                  LDS-DMA + lane-per-token variant lost to exposed LDS latency).
+//     QK^T         the lane's 16-byte chunk of each of the G query rows stays in registers (q is stationary);
+//                  v_dot2c_f32_bf16 partial dots, then a DPP butterfly over the LPT lanes of the row.
+//     softmax      exp2 domain; tile max per head = local max over the NI slots + DPP/permlane all-reduce
+//                  over the token-slot lanes (wavefront-level reductions, no LDS).
+//     PV           packed fp32 FMAs into acc[G][8] per lane.
+//     fold         token-slot lanes folded by one DPP step and a permlane reduce-scatter (one swap + one
+//                  add per two values); the 8 waves merge through a small LDS tile and the workgroup
+//                  writes one (max, sum, acc[G][D]) partial.
+//   combine kernel one thread per output element: every live partial requested in one round trip, merged,
+//                  normalised, rounded to bf16 (or kept fp32 for parity checks).
 // Grids depend only on static shapes; splits past context_lens[b] exit at once (graph-safe), block-table
-// entries past ceil(ctx/bs) are never read, cache offsets are 64-bit.
+// entries past ceil(ctx/bs) are never used, cache offsets are 64-bit.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -35,57 +37,42 @@ namespace nvh {
 
 namespace {
 
-constexpr int WAVES = 4;
-constexpr int WT = 64;                  // tokens per wave tile (one per lane in the QK^T phase)
-constexpr int SPLIT = WAVES * WT;       // tokens per workgroup
+// Diagnostic build only (-DNVH_STAMPS, tools/probes/stamp_decode.py): clock stamps per wave into a debug
+// buffer that nothing else reads.  Never compiled into the shipped library.
+#ifdef NVH_STAMPS
+#define NVH_STAMP(k)                                                                                     \
+    do {                                                                                                 \
+        unsigned long long t_;                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (a.stamps && lane == 0)                                                                       \
+            a.stamps[(((int64_t)b * gridDim.y + kh) * gridDim.x + split) * (WAVES * 8) + wave * 8 + (k)] = t_; \
+    } while (0)
+#else
+#define NVH_STAMP(k) do {} while (0)
+#endif
+
+constexpr int WAVES = 8;                        // VALU kernel: waves per workgroup
+constexpr int NI = 4;                           // VALU kernel: K (and V) load instructions per wave tile
 
 template <int D>
 struct Geo {
-    static constexpr int LPT = D / 8;           // lanes per token row in a coalesced load (16 B per lane)
+    static constexpr int LPT = D / 8;           // lanes per token row (16 B per lane)
     static constexpr int TPI = 64 / LPT;        // token rows per wave load instruction
-    static constexpr int NI = WT / TPI;         // load instructions per tile (K and V each): 8 / 16
-    static constexpr int ROWB = D * 2;          // bytes per token row in the LDS K image
-    static constexpr int ROWS = 4;              // partial sets a wave leaves in LDS (one per 16-lane row)
+    static constexpr int WT = NI * TPI;         // tokens per wave tile: 32 (D=64) / 16 (D=128)
+    static constexpr int SPLIT = WAVES * WT;    // tokens per workgroup: 256 / 128
 };
 
-// swizzle of the 16-byte chunk index inside token row T (conflict-free per-token ds_read_b128)
-template <int LPT>
-__device__ __forceinline__ int chunk_swizzle(int T) {
-    return LPT == 8 ? ((T >> 1) & 7) : (T & 15);
-}
-
-__device__ __forceinline__ float wave_max(float x) {
-    x = fmaxf(x, pair_in_row<1>(x));
-    x = fmaxf(x, pair_in_row<2>(x));
-    x = fmaxf(x, pair_in_row<4>(x));
-    x = fmaxf(x, pair_in_row<8>(x));
-    {   // rows 1,3 <-> rows 0,2
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    {   // lanes 32..63 <-> lanes 0..31
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-        x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-    }
-    return x;
-}
-
 template <int D, int G>
-__global__ __launch_bounds__(256) void paged_decode_split_kernel(const DecodeArgs a) {
+__global__ __launch_bounds__(WAVES * 64) void paged_decode_split_valu_kernel(const DecodeArgs a) {
     using geo = Geo<D>;
-    constexpr int LPT = geo::LPT, TPI = geo::TPI, NI = geo::NI, ROWB = geo::ROWB, ROWS = geo::ROWS;
-    constexpr int K_BYTES = WT * ROWB;                       // per wave: 8 KiB (D=64) / 16 KiB (D=128)
-    constexpr int FIN_BYTES = ROWS * G * D * 4;              // per wave, aliases its K image
-    static_assert(FIN_BYTES <= K_BYTES, "epilogue partials must fit in the wave's K image");
-    constexpr int P_BYTES = WT * 8 * 4;                      // per wave: p[token][8 heads] fp32
-    constexpr int QN = LPT * G;                              // 16-byte q chunks of the group: [chunk][head]
-    constexpr int QI = (QN + 63) / 64;                       // LDS-DMA instructions to fetch them
-    constexpr int Q_BYTES = QI * 1024;                       // per wave (each wave keeps its own copy: no barrier)
-    constexpr int WAVE_BYTES = K_BYTES + P_BYTES + Q_BYTES;
-    // one LDS array (a second __shared__ object next to LDS-DMA staging can force vmcnt(0) waits)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WAVES * WAVE_BYTES + WAVES * (8 * 4 + ROWS * 8 * 4)];
-    float* const lds_m = reinterpret_cast<float*>(lds + WAVES * WAVE_BYTES);     // [WAVES][8]
-    float* const lds_l = lds_m + WAVES * 8;                                       // [WAVES][ROWS][8]
+    constexpr int LPT = geo::LPT, TPI = geo::TPI, WT = geo::WT, SPLIT = geo::SPLIT;
+    constexpr int NV = G * 8;                                 // accumulator values per lane (multiple of 4)
+    constexpr int NQ = NV / 4;                                // values per lane after the reduce-scatter
+    constexpr int NH = 2 * NQ;
+    __shared__ __attribute__((aligned(16))) float lds_fin[WAVES][G * D];
+    __shared__ float lds_ml[WAVES][2][8];                     // [wave][max | sum][head]
 
     const int split = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x;
@@ -93,118 +80,81 @@ __global__ __launch_bounds__(256) void paged_decode_split_kernel(const DecodeArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wg_tok0 = split * SPLIT;
     const int tok0 = wg_tok0 + wave * WT;
+    NVH_STAMP(0);
     // context length and this tile's block id are fetched together (the id is only USED if the tile is live)
-    int blk = tok0 / a.block_size;                                // WT divides block_size: one block per tile
+    int blk = tok0 / a.block_size;                            // WT divides block_size: one block per tile
     blk = blk < a.max_blocks ? blk : a.max_blocks - 1;
     const int ctx = a.context_lens[b];
     const int bid = a.block_tables[(int64_t)b * a.bt_row_stride + blk];
-    asm volatile("" ::"s"(bid), "s"(ctx));                        // both scalar loads in flight before the branch
-    if (wg_tok0 >= ctx) return;                                   // whole workgroup, before any barrier
+    asm volatile("" ::"s"(bid), "s"(ctx));                    // both scalar loads in flight before the branch
+    if (wg_tok0 >= ctx) return;                               // whole workgroup, before any barrier
+    NVH_STAMP(1);
 
-    const int j = lane % LPT;                                     // 16-byte chunk of a row (load / PV mapping)
-    const int sl = lane / LPT;                                    // token slot inside one load instruction
-    const int n_live = ctx - tok0;                                // live tokens of this wave's tile (may be <= 0)
-    const bool active = n_live > 0;                               // wave-uniform
-    unsigned char* const lds_k = lds + wave * WAVE_BYTES;
-    float* const lds_p = reinterpret_cast<float*>(lds_k + K_BYTES);
-    unsigned char* const lds_q = lds_k + K_BYTES + P_BYTES;
+    const int j = lane % LPT;                                 // 16-byte chunk of the row owned by this lane
+    const int sl = lane / LPT;                                // token slot inside one load instruction
+    const int n_live = ctx - tok0;                            // live tokens of this wave's tile (may be <= 0)
 
-    // ---- issue every load of the tile, branch-free: q and K by LDS-DMA (in that order), then V into VGPRs.
-    // Rows past the live range are clamped to the tile's last live row (finite data); their scores are
-    // masked and their probabilities are exactly 0, so what they load never reaches the output.
-    u32x4 vreg[NI];
-    if (active) {
+    if (n_live > 0) {                                         // wave-uniform
+        // ---- loads, branch-free: rows past the live range are clamped to the tile's last live row (finite
+        // data); their scores are masked to -inf so their probabilities are exactly 0.
         const int off0 = tok0 - (tok0 / a.block_size) * a.block_size;
-        const int64_t row = (int64_t)a.kvh * D;                    // elements per token (all kv heads)
-        const int64_t base = ((int64_t)bid * a.block_size + off0) * row + (int64_t)kh * D;
+        const int64_t row = (int64_t)a.kvh * D;               // elements per token (all kv heads)
+        const int64_t base = ((int64_t)bid * a.block_size + off0) * row + (int64_t)kh * D + j * 8;
         const uint16_t* kp = a.k_cache + base;
         const uint16_t* vp = a.v_cache + base;
-        const uint16_t* qp = a.q + (int64_t)b * a.q_row_stride + (int64_t)(kh * G) * D;
         const int last = n_live - 1;
-#pragma unroll
-        for (int i = 0; i < QI; ++i) {                             // LDS entry e = c*G + g  <-  q[head g][chunk c]
-            int e = i * 64 + lane;
-            e = e < QN ? e : QN - 1;
-            const int c = e / G, g = e - c * G;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp + g * D + c * 8),
-                                             (__attribute__((address_space(3))) void*)(lds_q + i * 1024), 16, 0, 0);
-        }
+        u32x4 kreg[NI], vreg[NI], qreg[G];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int T = i * TPI + sl;                            // token of this lane in instruction i
-            const int Tc = T < last ? T : last;
-            const int src_chunk = j ^ chunk_swizzle<LPT>(T);       // LDS position j of row T holds this chunk
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + Tc * row + src_chunk * 8),
-                                             (__attribute__((address_space(3))) void*)(lds_k + i * 1024), 16, 0, 0);
+            const int T = i * TPI + sl;
+            kreg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kp + (T < last ? T : last) * row));
+        }
+        {
+            const uint16_t* qp = a.q + (int64_t)b * a.q_row_stride + (int64_t)(kh * G) * D + j * 8;
+#pragma unroll
+            for (int g = 0; g < G; ++g) qreg[g] = *reinterpret_cast<const u32x4*>(qp + g * D);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int T = i * TPI + sl;
-            const int Tc = T < last ? T : last;
-            vreg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vp + Tc * row + j * 8));
+            vreg[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vp + (T < last ? T : last) * row));
         }
-        // q and K have landed once at most the NI V loads are still outstanding (vmcnt retires in order)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    }
+        __builtin_amdgcn_sched_barrier(0);                    // every load issued before any of the math below
+        NVH_STAMP(2);
 
-    float acc[G][8], lsum[G];
+        // ---- scores: sc[i][g] = scale*log2e * <q_g, k_token(i,sl)>, -inf for masked tokens
+        float sc[NI][G];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        lsum[g] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[g][e] = 0.f;
-    }
-
-    if (active) {
-        // ---- QK^T: lane = token `lane` of the tile
-        float sc[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) sc[g] = 0.f;
-        const int swz = chunk_swizzle<LPT>(lane);
-        // two chunks per iteration: enough LDS reads in flight to cover their latency, few enough live
-        // q registers (2 x G x 4) that the tile keeps >= 2 waves per SIMD
-#pragma unroll 2
-        for (int c = 0; c < LPT; ++c) {
-            const u32x4 kc = *reinterpret_cast<const u32x4*>(lds_k + lane * ROWB + ((c ^ swz) * 16));
+        for (int i = 0; i < NI; ++i) {
+            const bool live = i * TPI + sl < n_live;
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const u32x4 qc = *reinterpret_cast<const u32x4*>(lds_q + (c * G + g) * 16);   // broadcast
+                float d = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) sc[g] = dot2_bf16(kc[w], qc[w], sc[g]);
+                for (int w = 0; w < 4; ++w) d = dot2_bf16(kreg[i][w], qreg[g][w], d);
+                d = group_sum<LPT>(d);
+                sc[i][g] = live ? d * a.scale_log2 : -INFINITY;
             }
         }
-        // ---- softmax numerators against the tile max (log2 domain)
-        const bool live = lane < n_live;
-        float pr[8];
-#pragma unroll
-        for (int g = 0; g < 8; ++g) pr[g] = 0.f;
+        NVH_STAMP(3);
+        // ---- tile max per head: local over the NI slots, then over the token-slot lanes
+        float m[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            const float s = live ? sc[g] * a.scale_log2 : -INFINITY;
-            const float m = wave_max(s);                           // finite: token 0 of the tile is live
-            pr[g] = fast_exp2(s - m);
-            if (lane == 0) lds_m[wave * 8 + g] = m;
+            float mx = sc[0][g];
+#pragma unroll
+            for (int i = 1; i < NI; ++i) mx = fmaxf(mx, sc[i][g]);
+            m[g] = slot_max<LPT>(mx);                         // finite: token 0 of the tile is live
         }
-        *reinterpret_cast<f32x4*>(lds_p + lane * 8) = f32x4{pr[0], pr[1], pr[2], pr[3]};
-        if constexpr (G > 4) *reinterpret_cast<f32x4*>(lds_p + lane * 8 + 4) = f32x4{pr[4], pr[5], pr[6], pr[7]};
-        // (same wave writes and reads lds_p; the compiler orders the LDS accesses, no barrier needed)
-
-        // ---- PV: lane = (token slot sl, dim chunk j).  p of the next instruction's token is fetched one
-        // iteration ahead; the scheduling fences keep the compiler from hoisting all NI fetches at once.
-        auto load_p = [&](int i, float (&p)[8]) {
-            const int T = i * TPI + sl;
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(lds_p + T * 8);
-            p[0] = p0[0]; p[1] = p0[1]; p[2] = p0[2]; p[3] = p0[3];
-            if constexpr (G > 4) {
-                const f32x4 p1 = *reinterpret_cast<const f32x4*>(lds_p + T * 8 + 4);
-                p[4] = p1[0]; p[5] = p1[1]; p[6] = p1[2]; p[7] = p1[3];
-            }
-        };
-        float pcur[8], pnxt[8];
-        load_p(0, pcur);
+        NVH_STAMP(4);
+        // ---- p = 2^(s - m); PV
+        float acc[NV], lsum[8];
+#pragma unroll
+        for (int x = 0; x < NV; ++x) acc[x] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) lsum[g] = 0.f;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            if (i + 1 < NI) load_p(i + 1, pnxt);
             float vf[8];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -213,57 +163,64 @@ __global__ __launch_bounds__(256) void paged_decode_split_kernel(const DecodeArg
             }
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                lsum[g] += pcur[g];
+                const float p = fast_exp2(sc[i][g] - m[g]);
+                lsum[g] += p;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[g][e] = fmaf(pcur[g], vf[e], acc[g][e]);
+                for (int e = 0; e < 8; ++e) acc[g * 8 + e] = fmaf(p, vf[e], acc[g * 8 + e]);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int g = 0; g < 8; ++g) pcur[g] = pnxt[g];
         }
-        // ---- fold token slots: inside a 16-lane row by DPP (D=64 only: two slots per row), rows via LDS
+        NVH_STAMP(5);
+        // ---- fold the token-slot lanes.  D=64: two slots share a 16-lane row -> one DPP step first.
         if constexpr (LPT == 8) {
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                lsum[g] += pair_in_row<8>(lsum[g]);
+            for (int x = 0; x < NV; ++x) acc[x] += pair_in_row<8>(acc[x]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[g][e] += pair_in_row<8>(acc[g][e]);
-            }
+            for (int g = 0; g < G; ++g) lsum[g] += pair_in_row<8>(lsum[g]);
         }
-        const int rowi = lane >> 4;
-        float* const fin = reinterpret_cast<float*>(lds_k) + rowi * (G * D);          // aliases this wave's K image
-        if ((lane & 15) < LPT) {                                   // one representative lane per (row, chunk)
+        // reduce-scatter over the 4 rows: afterwards row r of the wave holds accumulator values
+        // r*NQ .. r*NQ+NQ-1 and heads 2r, 2r+1 of lsum, each summed over all rows.
+        float h32[NH], fin[NQ];
 #pragma unroll
-            for (int g = 0; g < G; ++g) {
-                *reinterpret_cast<f32x4*>(fin + g * D + j * 8) = f32x4{acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
-                *reinterpret_cast<f32x4*>(fin + g * D + j * 8 + 4) = f32x4{acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
+        for (int x = 0; x < NH; ++x) h32[x] = fold32(acc[x], acc[x + NH]);
+#pragma unroll
+        for (int x = 0; x < NQ; ++x) fin[x] = fold16(h32[x], h32[x + NQ]);
+        float l32[4], lfin[2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) l32[x] = fold32(lsum[x], lsum[x + 4]);
+#pragma unroll
+        for (int x = 0; x < 2; ++x) lfin[x] = fold16(l32[x], l32[x + 2]);
+
+        const int rowi = lane >> 4;
+        if ((lane & 15) < LPT) {                              // one representative lane per (row, chunk)
+#pragma unroll
+            for (int x = 0; x < NQ; ++x) {
+                const int v = rowi * NQ + x;                  // flat accumulator index g*8 + e
+                lds_fin[wave][(v >> 3) * D + j * 8 + (v & 7)] = fin[x];
             }
             if (j == 0) {
+                lds_ml[wave][1][2 * rowi] = lfin[0];
+                lds_ml[wave][1][2 * rowi + 1] = lfin[1];
+                if (rowi == 0) {
 #pragma unroll
-                for (int g = 0; g < G; ++g) lds_l[(wave * ROWS + rowi) * 8 + g] = lsum[g];
+                    for (int g = 0; g < G; ++g) lds_ml[wave][0][g] = m[g];
+                }
             }
         }
+        NVH_STAMP(6);
     }
     __syncthreads();
 
-    // ---- merge rows and waves, write the workgroup's partial
-    const int n_waves = min(WAVES, (ctx - wg_tok0 + WT - 1) / WT); // live waves of this workgroup
-    for (int idx = tid; idx < G * D; idx += 256) {
+    // ---- merge the live waves with their own maxima, write the workgroup's partial
+    const int n_waves = min(WAVES, (ctx - wg_tok0 + WT - 1) / WT);
+    for (int idx = tid; idx < G * D; idx += WAVES * 64) {
         const int g = idx / D, d = idx - g * D;
         float M = -INFINITY;
-        for (int w = 0; w < n_waves; ++w) M = fmaxf(M, lds_m[w * 8 + g]);
+        for (int w = 0; w < n_waves; ++w) M = fmaxf(M, lds_ml[w][0][g]);
         float o = 0.f, L = 0.f;
         for (int w = 0; w < n_waves; ++w) {
-            const float f = fast_exp2(lds_m[w * 8 + g] - M);
-            const float* fw = reinterpret_cast<const float*>(lds + w * WAVE_BYTES) + g * D + d;
-            float so = 0.f, sl_ = 0.f;
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                so += fw[r * (G * D)];
-                sl_ += lds_l[(w * ROWS + r) * 8 + g];
-            }
-            o = fmaf(so, f, o);
-            L = fmaf(sl_, f, L);
+            const float f = fast_exp2(lds_ml[w][0][g] - M);
+            o = fmaf(lds_fin[w][idx], f, o);
+            L = fmaf(lds_ml[w][1][g], f, L);
         }
         const int64_t part = ((int64_t)b * a.h + kh * G + g) * a.num_splits + split;
         a.ws_acc[part * D + d] = o;
@@ -272,19 +229,240 @@ __global__ __launch_bounds__(256) void paged_decode_split_kernel(const DecodeArg
             a.ws_ml[part * 2 + 1] = L;
         }
     }
+    NVH_STAMP(7);
+}
+
+// =====================================================================================================
+// MFMA split kernel (default).  Under GQA the G query rows that share a kv head form a dense
+// [G x D].[D x T] contraction per (sequence, kv head): G is padded to the 16 columns of
+// v_mfma_f32_16x16x32_bf16 and the tile costs 8 + 16 MFMAs per 64 tokens instead of ~2000 VALU issues
+// (measured: the VALU kernel below is issue-bound at 11.6-13.9 us per layer).
+//   grid (num_splits, KVH, B), 256 threads = 4 waves; a workgroup owns SPLIT tokens, a wave a tile of WT.
+//   K, V and q are staged through LDS by LDS-DMA (global_load_lds_dwordx4): every wave instruction moves
+//   1 KiB = whole token rows, fully coalesced, no VGPR round trip.  Images are row-major; the 16-byte chunk
+//   order inside a row is XOR-swizzled on the SOURCE address so the MFMA operand reads are conflict free.
+//   S^T = K Q^T   A = K rows (ds_read_b128), B = the group's q rows.  C: lane l, reg r holds
+//                 S^T[token 4(l>>4)+r][head l&15]: per-head max/sum = local ops + 2 permlane steps.
+//   O^T = V^T P^T B = P^T straight from the S^T accumulators (split hi + lo bf16, so P keeps ~16 mantissa
+//                 bits and the 1e-3 parity bar holds at |o| ~ 3); A = V^T by ds_read_b64_tr_b16.
+//   The 4 waves merge through LDS (aliasing the wave's K image) into one partial per workgroup.
+constexpr int MW = 4;
+
+template <int D>
+struct MGeo {
+    static constexpr int LPT = D / 8;            // 16-byte chunks per token row
+    static constexpr int TPI = 64 / LPT;         // rows per LDS-DMA instruction (1 KiB)
+    static constexpr int WT = 4096 / D;          // tokens per wave tile: 64 (D=64) / 32 (D=128) -> 8 KiB images
+    static constexpr int NI = WT / TPI;          // DMA instructions per image (8)
+    static constexpr int ROWB = D * 2;           // bytes per row
+    static constexpr int NT = WT / 16;           // 16-token MFMA tiles of S^T
+    static constexpr int NHALF = WT / 32;        // 32-token groups of the PV contraction
+    static constexpr int STEPS = D / 32;         // k-steps of QK^T
+    static constexpr int DT = D / 16;            // 16-dim tiles of O^T
+    static constexpr int QI = 16 / TPI;          // DMA instructions for the 16-row q image
+    static constexpr int IMG = WT * ROWB;        // 8192
+    static constexpr int WAVE_BYTES = 2 * IMG;   // K + V image per wave; the q image is shared by the workgroup
+    static constexpr int SPLIT = MW * WT;
+};
+
+// swizzle of the 16-byte chunk position inside row T of an LDS image
+template <int LPT>
+__device__ __forceinline__ int chunk_swizzle(int T) {
+    return LPT == 8 ? ((T >> 1) & 7) : (T & 15);
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+__global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const DecodeArgs a, const int G) {
+    using geo = MGeo<D>;
+    constexpr int LPT = geo::LPT, TPI = geo::TPI, WT = geo::WT, NI = geo::NI, ROWB = geo::ROWB, NT = geo::NT;
+    constexpr int NHALF = geo::NHALF, STEPS = geo::STEPS, DT = geo::DT, QI = geo::QI, IMG = geo::IMG;
+    constexpr int WAVES = MW, SPLIT = geo::SPLIT;
+    static_assert(16 * D * 4 <= IMG, "merge tile must fit in the wave's K image");
+    // one LDS array (a second __shared__ object beside LDS-DMA staging can force vmcnt(0) waits)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MW * geo::WAVE_BYTES + QI * 1024 + MW * 2 * 16 * 4];
+    // every wave DMAs the same q bytes into this one image (identical writes; each wave waits on its own DMA)
+    unsigned char* const lds_q = lds + MW * geo::WAVE_BYTES;
+    float* const lds_ml = reinterpret_cast<float*>(lds_q + QI * 1024);              // [wave][max | sum][16 heads]
+
+    const int split = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg_tok0 = split * SPLIT;
+    const int tok0 = wg_tok0 + wave * WT;
+    NVH_STAMP(0);
+    int blk = tok0 / a.block_size;                            // WT divides block_size: one block per tile
+    blk = blk < a.max_blocks ? blk : a.max_blocks - 1;
+    const int ctx = a.context_lens[b];
+    const int bid = a.block_tables[(int64_t)b * a.bt_row_stride + blk];
+    asm volatile("" ::"s"(bid), "s"(ctx));                    // both scalar loads in flight before the branch
+    if (wg_tok0 >= ctx) return;                               // whole workgroup, before any barrier
+    NVH_STAMP(1);
+
+    const int n_live = ctx - tok0;                            // live tokens of this wave's tile (may be <= 0)
+    unsigned char* const lds_k = lds + wave * geo::WAVE_BYTES;
+    unsigned char* const lds_v = lds_k + IMG;
+    const int lq = lane & 15;                                 // head column of the MFMA tiles
+    const int lg = lane >> 4;                                 // lane group: k-block of operands / row block of C
+
+    if (n_live > 0) {                                         // wave-uniform; EXEC stays all ones inside
+        // ---- LDS-DMA, branch-free: q (16 rows, rows >= G repeat the last head), then K, then V.  Rows past the
+        // live range repeat the tile's last live row (finite data): their scores are masked, p is exactly 0.
+        {
+            const int p = lane % LPT, r = lane / LPT;         // chunk position / row inside one DMA instruction
+            const int off0 = tok0 - (tok0 / a.block_size) * a.block_size;
+            const int64_t row = (int64_t)a.kvh * D;           // elements per token (all kv heads)
+            const int64_t base = ((int64_t)bid * a.block_size + off0) * row + (int64_t)kh * D;
+            const uint16_t* kp = a.k_cache + base;
+            const uint16_t* vp = a.v_cache + base;
+            const uint16_t* qp = a.q + (int64_t)b * a.q_row_stride + (int64_t)(kh * G) * D;
+            const int last = n_live - 1;
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {
+                const int R = i * TPI + r;
+                const int g = R < G ? R : G - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp + g * D + (p ^ chunk_swizzle<LPT>(R)) * 8),
+                                                 (__attribute__((address_space(3))) void*)(lds_q + i * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int T = i * TPI + r;
+                const int Tc = T < last ? T : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kp + Tc * row + (p ^ chunk_swizzle<LPT>(T)) * 8),
+                                                 (__attribute__((address_space(3))) void*)(lds_k + i * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int T = i * TPI + r;
+                const int Tc = T < last ? T : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vp + Tc * row + (p ^ chunk_swizzle<LPT>(T)) * 8),
+                                                 (__attribute__((address_space(3))) void*)(lds_v + i * 1024), 16, 0, 0);
+            }
+        }
+        NVH_STAMP(2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");          // q and K landed; V may still be in flight
+        NVH_STAMP(3);
+
+        // ---- S^T = K Q^T
+        bf16x8 qf[STEPS];
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st)
+            qf[st] = *reinterpret_cast<const bf16x8*>(lds_q + lq * ROWB + (((4 * st + lg) ^ chunk_swizzle<LPT>(lq)) * 16));
+        f32x4 sT[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+            sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int R = 16 * tt + lq;
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds_k + R * ROWB + (((4 * st + lg) ^ chunk_swizzle<LPT>(R)) * 16));
+                sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
+            }
+        }
+        // ---- softmax numerators against the tile max of this lane's head (log2 domain)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool live = 16 * tt + 4 * lg + r < n_live;
+                sT[tt][r] = live ? sT[tt][r] * a.scale_log2 : -INFINITY;
+                mx = fmaxf(mx, sT[tt][r]);
+            }
+        mx = max_xor16(mx);
+        mx = max_xor32(mx);                                    // finite: token 0 of the tile is live
+        float lsum = 0.f;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                sT[tt][r] = fast_exp2(sT[tt][r] - mx);
+                lsum += sT[tt][r];
+            }
+        NVH_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // V landed
+        NVH_STAMP(5);
+
+        // ---- O^T += V^T P^T, P as hi + lo bf16
+        f32x4 o[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int vq = lq >> 2, vp = lq & 3;                  // lane 4q+p of its group addresses key row q, dims 4p..4p+3
+#pragma unroll
+        for (int hh = 0; hh < NHALF; ++hh) {
+            bf16x8 p_hi, p_lo;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float pv = sT[2 * hh + (i >> 2)][i & 3];
+                p_hi[i] = (__bf16)pv;
+                p_lo[i] = (__bf16)(pv - (float)p_hi[i]);
+            }
+            const int R = 32 * hh + 4 * lg + vq;              // chunk_swizzle(R) == chunk_swizzle(R + 16)
+            const unsigned char* vrow = lds_v + R * ROWB + (vp & 1) * 8;
+            const int swz = chunk_swizzle<LPT>(R);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                const int off = ((2 * t + (vp >> 1)) ^ swz) * 16;
+                const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vrow + off));
+                const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(vrow + 16 * ROWB + off));
+                const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi, o[t], 0, 0, 0);
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo, o[t], 0, 0, 0);
+            }
+        }
+        lsum = sum_xor16(lsum);
+        lsum = sum_xor32(lsum);
+        NVH_STAMP(6);
+        // ---- this wave's (max, sum, O) into LDS: O^T[dim 16t+4lg+r][head lq] -> fin[head][dim], aliasing the K image
+        if (lq < G) {
+            float* const fin = reinterpret_cast<float*>(lds_k) + lq * D + 4 * lg;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) *reinterpret_cast<f32x4*>(fin + 16 * t) = o[t];
+            if (lg == 0) {
+                lds_ml[(wave * 2 + 0) * 16 + lq] = mx;
+                lds_ml[(wave * 2 + 1) * 16 + lq] = lsum;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- merge the live waves with their own maxima, write the workgroup's partial
+    const int n_waves = min(WAVES, (ctx - wg_tok0 + WT - 1) / WT);
+    for (int idx = tid; idx < G * D; idx += WAVES * 64) {
+        const int g = idx / D, d = idx - g * D;
+        float M = -INFINITY;
+        for (int w = 0; w < n_waves; ++w) M = fmaxf(M, lds_ml[(w * 2 + 0) * 16 + g]);
+        float o = 0.f, L = 0.f;
+        for (int w = 0; w < n_waves; ++w) {
+            const float f = fast_exp2(lds_ml[(w * 2 + 0) * 16 + g] - M);
+            o = fmaf(reinterpret_cast<const float*>(lds + w * geo::WAVE_BYTES)[idx], f, o);
+            L = fmaf(lds_ml[(w * 2 + 1) * 16 + g], f, L);
+        }
+        const int64_t part = ((int64_t)b * a.h + kh * G + g) * a.num_splits + split;
+        a.ws_acc[part * D + d] = o;
+        if (d == 0) {
+            a.ws_ml[part * 2] = M;
+            a.ws_ml[part * 2 + 1] = L;
+        }
+    }
+    NVH_STAMP(7);
 }
 
 // One thread per output element (b, h, d): all live partials are requested before any is used.
 template <int D>
 __global__ __launch_bounds__(256) void paged_decode_combine_kernel(const DecodeArgs a) {
-    constexpr int CH = 16;                                         // partials per unrolled round trip
+    constexpr int SPLIT = Geo<D>::SPLIT;
+    constexpr int CH = 16;                                     // partials per unrolled round trip
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)a.batch * a.h * D) return;
     const int64_t bh = idx / D;
     const int d = (int)(idx - bh * D);
     const int b = (int)(bh / a.h);
     const int ctx = a.context_lens[b];
-    const int n = (ctx + SPLIT - 1) / SPLIT;                       // live splits; 0 for padding rows
+    const int n = (ctx + SPLIT - 1) / SPLIT;                   // live splits; 0 for padding rows
     const float* ml = a.ws_ml + bh * a.num_splits * 2;
     const float* pa = a.ws_acc + bh * a.num_splits * D + d;
     float M = -INFINITY, o = 0.f, L = 0.f;
@@ -300,7 +478,7 @@ __global__ __launch_bounds__(256) void paged_decode_combine_kernel(const DecodeA
         float Mc = M;
 #pragma unroll
         for (int i = 0; i < CH; ++i) Mc = fmaxf(Mc, mv[i]);
-        const float fo = fast_exp2(M - Mc);                        // M = -inf on the first chunk -> 0
+        const float fo = fast_exp2(M - Mc);                    // M = -inf on the first chunk -> 0
         o *= fo;
         L *= fo;
 #pragma unroll
@@ -311,46 +489,71 @@ __global__ __launch_bounds__(256) void paged_decode_combine_kernel(const DecodeA
         }
         M = Mc;
     }
-    const float r = n > 0 ? o / L : 0.f;                           // ctx == 0 -> zeros (oracle behaviour)
+    const float r = n > 0 ? o / L : 0.f;                       // ctx == 0 -> zeros (oracle behaviour)
     if (a.out_f32) reinterpret_cast<float*>(a.out)[idx] = r;
     else reinterpret_cast<__bf16*>(a.out)[idx] = (__bf16)r;
 }
 
-template <int D, int G>
-int launch_dg(const DecodeArgs& a, hipStream_t stream) {
-    dim3 grid(a.num_splits, a.kvh, a.batch);
-    hipLaunchKernelGGL((paged_decode_split_kernel<D, G>), grid, dim3(256), 0, stream, a);
-    int rc = check_launch("paged_decode_split");
-    if (rc) return rc;
+template <int D>
+int launch_combine(const DecodeArgs& a, hipStream_t stream) {
     const int64_t total = (int64_t)a.batch * a.h * D;
     hipLaunchKernelGGL((paged_decode_combine_kernel<D>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, a);
     return check_launch("paged_decode_combine");
 }
 
+template <int D, int G>
+int launch_valu(const DecodeArgs& a, hipStream_t stream) {
+    dim3 grid(a.num_splits, a.kvh, a.batch);
+    hipLaunchKernelGGL((paged_decode_split_valu_kernel<D, G>), grid, dim3(WAVES * 64), 0, stream, a);
+    int rc = check_launch("paged_decode_split_valu");
+    return rc ? rc : launch_combine<D>(a, stream);
+}
+
 template <int D>
-int launch_d(const DecodeArgs& a, int g, hipStream_t stream) {
+int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
     switch (g) {
-        case 1: return launch_dg<D, 1>(a, stream);
-        case 2: return launch_dg<D, 2>(a, stream);
-        case 3: return launch_dg<D, 3>(a, stream);
-        case 4: return launch_dg<D, 4>(a, stream);
-        case 5: return launch_dg<D, 5>(a, stream);
-        case 6: return launch_dg<D, 6>(a, stream);
-        case 7: return launch_dg<D, 7>(a, stream);
-        case 8: return launch_dg<D, 8>(a, stream);
+        case 1: return launch_valu<D, 1>(a, stream);
+        case 2: return launch_valu<D, 2>(a, stream);
+        case 3: return launch_valu<D, 3>(a, stream);
+        case 4: return launch_valu<D, 4>(a, stream);
+        case 5: return launch_valu<D, 5>(a, stream);
+        case 6: return launch_valu<D, 6>(a, stream);
+        case 7: return launch_valu<D, 7>(a, stream);
+        case 8: return launch_valu<D, 8>(a, stream);
     }
-    set_error("paged_decode: group size %d not in 1..8", g);
+    set_error("paged_decode (valu): group size %d not in 1..8", g);
     return -2;
+}
+
+template <int D>
+int launch_mfma(const DecodeArgs& a, int g, hipStream_t stream) {
+    dim3 grid(a.num_splits, a.kvh, a.batch);
+    hipLaunchKernelGGL((paged_decode_split_mfma_kernel<D>), grid, dim3(MW * 64), 0, stream, a, g);
+    int rc = check_launch("paged_decode_split_mfma");
+    return rc ? rc : launch_combine<D>(a, stream);
 }
 
 }  // namespace
 
-int decode_split_tokens(int hd) { (void)hd; return SPLIT; }
+int decode_split_tokens(int hd) { return hd == 64 ? MGeo<64>::SPLIT : MGeo<128>::SPLIT; }
+static_assert(MGeo<64>::SPLIT == Geo<64>::SPLIT && MGeo<128>::SPLIT == Geo<128>::SPLIT, "both split kernels share one workspace layout");
+
+int decode_max_group(void) { return 16; }
+
+// NVH_DECODE_IMPL=valu selects the VALU split kernel (groups <= 8) for A/B measurements; default is MFMA.
+static bool use_valu() {
+    static const bool v = [] {
+        const char* e = getenv("NVH_DECODE_IMPL");
+        return e && e[0] == 'v';
+    }();
+    return v;
+}
 
 int launch_paged_decode(const DecodeArgs& a, hipStream_t stream) {
     if (a.batch == 0) return 0;
     const int g = a.h / a.kvh;
-    return a.hd == 64 ? launch_d<64>(a, g, stream) : launch_d<128>(a, g, stream);
+    if (use_valu() && g <= 8) return a.hd == 64 ? launch_valu_d<64>(a, g, stream) : launch_valu_d<128>(a, g, stream);
+    return a.hd == 64 ? launch_mfma<64>(a, g, stream) : launch_mfma<128>(a, g, stream);
 }
 
 }  // namespace nvh

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 sv[4 * t + r] = x;
                 mx = fmaxf(mx, x);
             }
-        mx = fmaxf(mx, xor16(mx));
-        mx = fmaxf(mx, xor32(mx));
+        mx = max_xor16(mx);
+        mx = max_xor32(mx);
         const float m_new = fmaxf(m_run, mx);
         // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
         const float m_use = m_new == -INFINITY ? 0.f : m_new;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     }
 
     // ---- finalise: total row sum over the 4 lane groups, normalise, store 4 contiguous dims per tile
-    l_run += xor16(l_run);
-    l_run += xor32(l_run);
+    l_run = sum_xor16(l_run);
+    l_run = sum_xor32(l_run);
     if (!q_ok) return;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     const int64_t orow = ((int64_t)(q_beg + my_q) * a.h + head) * D;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-wave phase timeline of the decode split kernel (s_memrealtime stamps, 10 ns ticks).
+Builds a SEPARATE library with -DNVH_STAMPS (tools/probes/libnvh_attn_stamps.so); the shipped library
+never contains stamp code.  Usage: python tools/probes/stamp_decode.py [--batch 32 --ctx 1536]"""
+import argparse, ctypes, os, subprocess, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "nano-vllm-learn_amd", "csrc")
+OUT = os.path.join(ROOT, "tools", "probes", "libnvh_attn_stamps.so")
+
+def build():
+    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip")]
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNVH_STAMPS",
+                    "-Wno-unused-command-line-argument", *srcs, "-o", OUT], check=True)
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=32); ap.add_argument("--ctx", type=int, default=1536)
+    ap.add_argument("--heads", type=int, default=14); ap.add_argument("--kv-heads", type=int, default=2)
+    ap.add_argument("--head-dim", type=int, default=64); ap.add_argument("--build-only", action="store_true")
+    args = ap.parse_args()
+    if args.build_only or not os.path.exists(OUT):
+        build()
+        if args.build_only: return
+    lib = ctypes.CDLL(OUT)
+    b, h, kvh, d, bs = args.batch, args.heads, args.kv_heads, args.head_dim, 256
+    nblk = (args.ctx + bs - 1) // bs
+    nb = b * nblk + 1
+    layers = 8
+    caches = [torch.randn(2, nb, bs, kvh, d, device="cuda", dtype=torch.bfloat16) for _ in range(layers)]
+    perm = torch.randperm(nb - 1)[: b * nblk].view(b, nblk).int().cuda()
+    cl = torch.full((b,), args.ctx, dtype=torch.int32, device="cuda")
+    q = torch.randn(b, h, d, device="cuda", dtype=torch.bfloat16)
+    out = torch.empty_like(q)
+    nsplit = (nblk * bs + 255) // 256
+    ws = torch.empty(b * h * nsplit * (d + 2) * 4, dtype=torch.uint8, device="cuda")
+    stamps = torch.zeros(b * kvh * nsplit * 32, dtype=torch.int64, device="cuda")
+    lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
+    lib.nvh_paged_decode.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    def call(l):
+        rc = lib.nvh_paged_decode(out.data_ptr(), q.data_ptr(), caches[l][0].data_ptr(), caches[l][1].data_ptr(), perm.data_ptr(), cl.data_ptr(),
+                                  b, h, kvh, d, bs, nblk, h * d, nblk, d ** -0.5, 0, 0, ws.data_ptr(), ws.numel(), None)
+        assert rc == 0, rc
+    for rep in range(3):
+        for l in range(layers): call(l)
+    torch.cuda.synchronize()
+    st = stamps.cpu().numpy().reshape(-1, 4, 8).astype(np.float64) * 0.01     # us
+    t0 = st[:, :, 0].min()
+    names = ["start", "scalars+branch", "loads issued", "K landed (vmcnt 8)", "QK+softmax done", "V landed (vmcnt 0)", "PV done", "epilogue+merge done"]
+    print(f"workgroups {st.shape[0]}, kernel span {st[:, :, 7].max() - t0:.2f} us (first wave start -> last wave end)")
+    for k, n in enumerate(names):
+        v = st[:, :, k] - t0
+        print(f"  {k} {n:<22} abs: min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}"
+              + ("" if k == 0 else f"   delta vs prev: med {np.median(st[:, :, k] - st[:, :, k-1]):5.2f} max {(st[:, :, k] - st[:, :, k-1]).max():5.2f}"))
+if __name__ == "__main__":
+    main()
