@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py — decode tok/s of the `hip` attention backend in a bench_my.py-shaped run (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): Qwen2-0.5B shapes, random-init bf16 weights, bs=32 sequences of
+1024 random prompt tokens (`random.seed(0)`, `randint(0, 10000)`, bench_my.py:27-40), greedy decode with
+ignore_eos.  A "step" is one decode step of the whole batch through all 24 layers: per layer one
+store_kvcache + paged-decode attention call through the C ABI (the hot path) plus the PyTorch-ROCm model
+body around it, replayed from a HIP graph with device-resident metadata.  Prefill runs before the timed
+region (it is reported separately, and the bench_my-style figure that includes it is in `bench_my_tok_s`).
+The K timed steps start at context 1025 as bench_my's decode phase does (K = 1024 covers 1025 -> 2048).
+
+Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the decode attention op (nvh_decode_step: store + split-KV attention + combine) at the mean
+                context of the timed window, timed live with HIP events on the launching stream over a graph
+                of per-layer calls on distinct caches; achieved = algorithmic bytes / average time per call.
+  cpu_baseline  the CPU port of the reference's sdpa.math decode (oracle/sdpa_math_cpu.py, "port"), timed on
+                this host on a bounded sample of the same attention call; rank 0, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from random import randint, seed
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "nano-vllm-learn_amd"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def decode_attn_bytes(ctxs, h, kvh, d, bs=256, with_store=True):
+    """Algorithmic bytes of one decode attention call, per rank."""
+    ctxs = np.asarray(ctxs, dtype=np.int64)
+    b = len(ctxs)
+    n = int((2 * ctxs * kvh * d * 2).sum() + 2 * b * h * d * 2 + 4 * (np.ceil(ctxs / bs).sum() + b))
+    if with_store:
+        n += 4 * b * kvh * d * 2
+    return n
+
+
+@torch.inference_mode()
+def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
+    """Time nvh_decode_step alone: a HIP graph of `layers` calls on distinct KV caches (no Infinity-Cache reuse
+    between calls), replayed `iters` times between two HIP events on the launching stream."""
+    from nanovllm_hip import ops
+    dev = torch.device("cuda", torch.cuda.current_device())
+    h, kvh, d, bs = cfg.num_attention_heads // tp, max(cfg.num_key_value_heads // tp, 1), cfg.head_dim, cfg.kvcache_block_size
+    nblk = (ctx + bs - 1) // bs
+    nb = batch * nblk + 1
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    caches = [torch.randn(2, nb, bs, kvh, d, device=dev, dtype=torch.bfloat16) for _ in range(layers)]
+    bt = torch.randperm(nb - 1, generator=gen)[: batch * nblk].view(batch, nblk).int().to(dev)
+    cl = torch.full((batch,), ctx, dtype=torch.int32, device=dev)
+    slots = (bt[:, (ctx - 1) // bs].long() * bs + (ctx - 1) % bs).int()
+    qkv = torch.randn(batch, (h + 2 * kvh) * d, device=dev, dtype=torch.bfloat16)
+    q, k, v = qkv[:, :h * d].view(batch, h, d), qkv[:, h * d:(h + kvh) * d].view(batch, kvh, d), qkv[:, (h + kvh) * d:].view(batch, kvh, d)
+    out = torch.empty(batch, h, d, device=dev, dtype=torch.bfloat16)
+    ops.reserve_workspace(dev, ops.decode_workspace_bytes(batch, h, d, nblk, bs))
+
+    def calls():
+        for c in caches:
+            ops.decode_step(q, k, v, c[0], c[1], slots, cl, bt, out=out)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        calls()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        calls()
+    for _ in range(3):
+        graph.replay()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        graph.replay()
+    end.record()
+    torch.cuda.synchronize()
+    us = start.elapsed_time(end) * 1e3 / (iters * layers)
+    nbytes = decode_attn_bytes([ctx] * batch, h, kvh, d, bs)
+    return us, nbytes
+
+
+def cpu_baseline_leg(cfg, batch, ctx, budget_s=12.0):
+    """Time the CPU port of the reference's sdpa.math decode call (one layer, bf16 like the reference) on the host."""
+    from oracle.sdpa_math_cpu import flash_attn_with_kvcache_cpu
+    h, kvh, d, bs = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.kvcache_block_size
+    nblk = (ctx + bs - 1) // bs
+    nb = batch * nblk + 1
+    gen = torch.Generator().manual_seed(0)
+    kc = torch.randn(nb, bs, kvh, d, generator=gen).bfloat16()
+    vc = torch.randn(nb, bs, kvh, d, generator=gen).bfloat16()
+    q = torch.randn(batch, 1, h, d, generator=gen).bfloat16()
+    bt = torch.randperm(nb - 1, generator=gen)[: batch * nblk].view(batch, nblk).int()
+    cl = torch.full((batch,), ctx, dtype=torch.int32)
+    flash_attn_with_kvcache_cpu(q, kc, vc, cl, bt)                      # warm-up
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        flash_attn_with_kvcache_cpu(q, kc, vc, cl, bt)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 40:
+            break
+    per_call = el / reps
+    layers = cfg.num_hidden_layers
+    return {"value": round(batch / (per_call * layers), 2), "unit": "tok/s (attention path only: one decode step = %d layer calls)" % layers,
+            "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} calls of the sdpa.math decode attention (B={batch}, ctx={ctx}, H/KVH/D={h}/{kvh}/{d}, bf16) in {el:.1f} s; "
+                      f"{per_call * 1e3:.1f} ms per layer call; host cpu_count={os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--model", default="Qwen2-0.5B")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--input-len", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="no HIP graph (debug)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hip attention backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from nanovllm_hip.engine.llm_engine import LLMEngine
+    from nanovllm_hip.engine.sequence import Sequence
+    from nanovllm_hip.models.qwen import model_config
+
+    cfg = model_config(args.model)
+    bs = cfg.kvcache_block_size
+    total_len = args.input_len + args.steps + args.warmup + 2
+    blocks_per_seq = (total_len + bs - 1) // bs
+    engine = LLMEngine(cfg, num_kvcache_blocks=args.batch * blocks_per_seq + 8, max_model_len=max(4096, total_len),
+                       enforce_eager=args.eager, seed=0)
+
+    seed(0)
+    prompts = [[randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.batch)]
+    seqs = [Sequence(p, max_tokens=args.steps + 1) for p in prompts]
+
+    # ---- prefill (outside the timed decode region; timed on its own)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    engine.prefill(seqs, reserve_tokens=args.steps + args.warmup + 2)
+    torch.cuda.synchronize()
+    prefill_s = time.perf_counter() - t0
+    ctx0 = len(seqs[0])                                               # input_len + 1: first decode step's context
+
+    # ---- decode: W untimed steps, rewind to the same context, then exactly K timed steps
+    sess = engine.runner.decode_session(seqs, args.steps + args.warmup + 1, use_graph=not args.eager)
+    state0 = sess.state()
+    sess.step(args.warmup)
+    sess.rewind(state0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sess.step(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tok_s = args.batch * args.steps / elapsed
+
+    # ---- roofline leg: the attention op alone at the mean context of the timed window
+    mean_ctx = ctx0 + (args.steps - 1) // 2
+    tp = world
+    attn_us, attn_bytes = attention_leg(cfg, tp, args.batch, mean_ctx, cfg.num_hidden_layers)
+    achieved = attn_bytes / attn_us / 1e3                              # GB/s
+
+    result = None
+    if rank == 0:
+        kvh_r = max(cfg.num_key_value_heads // tp, 1)
+        weight_bytes = sum(p.numel() * p.element_size() for p in engine.runner.model.parameters())
+        step_bytes = weight_bytes + cfg.num_hidden_layers * attn_bytes
+        step_us = elapsed / args.steps * 1e6
+        result = {
+            "metric": "decode tok/s (bench_my.py) Qwen2-0.5B bs=32 in=out=1024; % HBM roofline" if args.model == "Qwen2-0.5B" and args.batch == 32
+                      else f"decode tok/s (bench_my.py-shaped) {args.model} bs={args.batch}",
+            "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random prompts randint(0,10000) seed 0; random-init weights N(0,0.02) seed 0)",
+            "config": {"workload": f"{args.model} bs={args.batch} in={args.input_len} decode steps={args.steps} --attn-backend hip, "
+                                   f"TP={tp}, HIP-graph replay, device-resident metadata",
+                       "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "nvh_decode_step = store_kvcache + paged_decode_split_mfma + paged_decode_combine (one attention call)",
+                         "bytes_per_launch": attn_bytes, "us_per_launch": round(attn_us, 2), "context": mean_ctx,
+                         "shape_per_rank": [cfg.num_attention_heads // tp, kvh_r, cfg.head_dim]},
+            "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),
+                                     "frac": round(step_bytes / 8e6 / step_us, 4),
+                                     "attention_share_of_step": round(cfg.num_hidden_layers * attn_us / step_us, 3)},
+            "prefill_s": round(prefill_s, 4),
+            "bench_my_tok_s": round(args.batch * (args.steps + 1) / (prefill_s + elapsed), 1),
+            "attention_only_tok_s": round(args.batch / (attn_us * 1e-6 * cfg.num_hidden_layers), 1),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, ROOT)
+            result["cpu_baseline"] = cpu_baseline_leg(cfg, args.batch, mean_ctx)
+        else:
+            result["cpu_baseline"] = None
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

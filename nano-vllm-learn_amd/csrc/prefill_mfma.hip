@@ -17,6 +17,7 @@
 //   O^T = V^T P^T   B = P^T straight from the S^T accumulators of the two 16-key halves (k-slot j<4 ->
 //                   key 4g+j, j>=4 -> key 16+4g+j-4, g = l>>4); A = V^T in the SAME k order, produced by
 //                   ds_read_b64_tr_b16 (hardware transpose of a 4-key x 16-dim block) from row-major V.
+//                   P enters as hi + lo bf16 halves (two MFMAs per tile) so it keeps ~16 mantissa bits.
 //                   C layout: lane l, reg r holds O^T[dim 16t+4(l>>4)+r][query l&15] -> 4 contiguous
 //                   output dims per lane.
 // Algorithmic flops per launch: sum_seq 4*D*H*(causal pairs); bytes: Tq*H*D*2*2 + Tk*KVH*D*2*2.
@@ -148,9 +149,13 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         m_run = m_new;
 #pragma unroll
         for (int t = 0; t < DT; ++t) o[t] *= alpha;
-        bf16x8 pf;
+        // P as hi + lo bf16 (~16 mantissa bits): a single bf16 P costs ~4e-3 abs at |o| ~ 3, over the 1e-3 parity bar
+        bf16x8 pf, pf_lo;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pf[i] = (__bf16)pv[i];
+        for (int i = 0; i < 8; ++i) {
+            pf[i] = (__bf16)pv[i];
+            pf_lo[i] = (__bf16)(pv[i] - (float)pf[i]);
+        }
 
         // ---- O^T += V^T P^T
 #pragma unroll
@@ -162,6 +167,7 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
             const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base + 16 * ROWB));
             const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // whole-register concat, no repack
             o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
+            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf_lo, o[t], 0, 0, 0);
         }
     }
 

@@ -1,0 +1,216 @@
+"""Device boundary of the engine: KV-cache allocation and binding, the metadata producers that feed the
+attention path, eager execution, and a device-resident HIP-graph decode session.
+
+Mirrors nanovllm/engine/model_runner.py for the parts that produce attention inputs:
+  allocate_kv_cache      :124-157  one tensor [2, L, num_blocks, block_size, KVH/tp, D]; views bound to every
+                                   module that has k_cache / v_cache attributes
+  build_block_tables     :160-169  right-pad with -1
+  build_prefill_meta     :171-242
+  build_decode_meta      :244-269  (positions = len(seq): the reference's own convention)
+  run                    :278-313
+  DecodeSession          :281-303,316-370 re-thought for MI355X: instead of rebuilding five host tensors and
+                                   copying them in before each replay, the decode metadata lives on the device
+                                   and is advanced inside the captured graph (context_lens += 1, slot from the
+                                   block table), so a decode step is one graph replay and zero host work.
+                                   Padding rows carry slot -1 / context 0.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from .. import ops
+from ..models.qwen import ModelConfig, QwenForCausalLM
+from ..utils.context import reset_context, set_context
+from .sequence import Sequence
+
+
+# ----------------------------------------------------------------------------- metadata producers (host, CPU tensors)
+def build_block_tables(seqs, width=None, pad=-1):
+    width = width or max(len(s.block_table) for s in seqs)
+    rows = [s.block_table + [pad] * (width - len(s.block_table)) for s in seqs]
+    return torch.tensor(rows, dtype=torch.int32)
+
+
+def build_prefill_meta(seqs, block_size=256):
+    input_ids, positions, slot_mapping = [], [], []
+    cu_q, cu_k = [0], [0]
+    max_q = max_k = 0
+    for seq in seqs:
+        seqlen = len(seq)
+        input_ids.extend(seq[seq.num_cached_tokens:])
+        positions.extend(range(seq.num_cached_tokens, seqlen))
+        seqlen_q, seqlen_k = seqlen - seq.num_cached_tokens, seqlen
+        cu_q.append(cu_q[-1] + seqlen_q)
+        cu_k.append(cu_k[-1] + seqlen_k)
+        max_q, max_k = max(max_q, seqlen_q), max(max_k, seqlen_k)
+        if not seq.block_table:                      # warmup: no cache allocated yet
+            continue
+        for i in range(seq.num_cached_blocks, seq.num_blocks):
+            start = seq.block_table[i] * block_size
+            end = start + (block_size if i != seq.num_blocks - 1 else seq.last_block_num_tokens)
+            slot_mapping.extend(range(start, end))
+    block_tables = build_block_tables(seqs) if cu_k[-1] > cu_q[-1] else None      # prefix-cache hit somewhere
+    return dict(input_ids=torch.tensor(input_ids, dtype=torch.int64), positions=torch.tensor(positions, dtype=torch.int64),
+                cu_seqlens_q=torch.tensor(cu_q, dtype=torch.int32), cu_seqlens_k=torch.tensor(cu_k, dtype=torch.int32),
+                max_seqlen_q=max_q, max_seqlen_k=max_k, slot_mapping=torch.tensor(slot_mapping, dtype=torch.int32),
+                block_tables=block_tables)
+
+
+def build_decode_meta(seqs, block_size=256):
+    input_ids = [s.last_token for s in seqs]
+    positions = [len(s) for s in seqs]
+    context_lens = [len(s) for s in seqs]
+    slot_mapping = [s.block_table[s.num_blocks - 1] * block_size + s.last_block_num_tokens - 1 for s in seqs]
+    return dict(input_ids=torch.tensor(input_ids, dtype=torch.int64), positions=torch.tensor(positions, dtype=torch.int64),
+                slot_mapping=torch.tensor(slot_mapping, dtype=torch.int32), context_lens=torch.tensor(context_lens, dtype=torch.int32),
+                block_tables=build_block_tables(seqs))
+
+
+# ----------------------------------------------------------------------------- runner
+class ModelRunner:
+    def __init__(self, cfg: ModelConfig, num_kvcache_blocks: int, device=None, max_model_len=4096, seed=0):
+        self.cfg = cfg
+        self.block_size = cfg.kvcache_block_size
+        self.max_model_len = max_model_len
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.model = QwenForCausalLM(cfg).init_random(seed).to(device=self.device, dtype=torch.bfloat16)
+        self.model.eval()
+        self.num_kvcache_blocks = num_kvcache_blocks
+        self.allocate_kv_cache()
+
+    def allocate_kv_cache(self):
+        cfg = self.cfg
+        kvh = cfg.num_key_value_heads // self.world_size
+        self.kv_cache = torch.zeros(2, cfg.num_hidden_layers, self.num_kvcache_blocks, self.block_size, kvh, cfg.head_dim,
+                                    dtype=torch.bfloat16, device=self.device)
+        layer_id = 0
+        for module in self.model.modules():
+            if hasattr(module, "k_cache") and hasattr(module, "v_cache"):         # duck-typed, model_runner.py:151
+                module.k_cache = self.kv_cache[0, layer_id]
+                module.v_cache = self.kv_cache[1, layer_id]
+                layer_id += 1
+        assert layer_id == cfg.num_hidden_layers
+
+    def _dev(self, t):
+        return t.to(self.device, non_blocking=True) if t is not None else None
+
+    @torch.inference_mode()
+    def run(self, seqs, is_prefill):
+        """One eager forward (prefill, or a decode step with host-built metadata); returns greedy token ids."""
+        m = build_prefill_meta(seqs, self.block_size) if is_prefill else build_decode_meta(seqs, self.block_size)
+        if is_prefill:
+            set_context(True, self._dev(m["cu_seqlens_q"]), self._dev(m["cu_seqlens_k"]), m["max_seqlen_q"], m["max_seqlen_k"],
+                        self._dev(m["slot_mapping"]), None, self._dev(m["block_tables"]))
+        else:
+            set_context(False, slot_mapping=self._dev(m["slot_mapping"]), context_lens=self._dev(m["context_lens"]),
+                        block_tables=self._dev(m["block_tables"]))
+        hidden = self.model(self._dev(m["input_ids"]), self._dev(m["positions"]))
+        if is_prefill:
+            last = self._dev(m["cu_seqlens_q"])[1:].long() - 1                     # last token of every sequence (embed_head.py:62-65)
+            hidden = hidden[last]
+        tokens = self.model.compute_logits(hidden).argmax(dim=-1)
+        reset_context()
+        return tokens.tolist()
+
+    def decode_session(self, seqs, max_new_tokens, use_graph=True):
+        return DecodeSession(self, seqs, max_new_tokens, use_graph)
+
+
+class DecodeSession:
+    """Batched greedy decode of `seqs` for a fixed number of steps with device-resident metadata.
+
+    All blocks the sequences will need are already in their block tables (BlockManager.allocate(reserve_tokens=...)),
+    so block tables are static; per step the device advances input_ids / positions / context_lens / slot_mapping
+    itself.  The step is captured once into a HIP graph (torch.cuda.CUDAGraph on ROCm) and replayed."""
+
+    def __init__(self, runner: ModelRunner, seqs, max_new_tokens, use_graph=True):
+        self.runner, self.seqs, self.use_graph = runner, seqs, use_graph
+        dev, bs = runner.device, runner.block_size
+        b = len(seqs)
+        self.batch = b
+        need_tokens = max(len(s) for s in seqs) + max_new_tokens
+        width = (need_tokens + bs - 1) // bs
+        for s in seqs:
+            assert len(s.block_table) * bs >= len(s) + max_new_tokens, "reserve blocks for the whole generation first"
+        m = build_decode_meta(seqs, bs)
+        self.block_tables = build_block_tables(seqs, width=max(width, max(len(s.block_table) for s in seqs)), pad=0).to(dev)
+        self.input_ids = m["input_ids"].to(dev)
+        self.positions = m["positions"].to(dev)
+        self.context_lens = m["context_lens"].to(dev)
+        self.slot_mapping = m["slot_mapping"].to(dev)
+        self.tokens = torch.zeros(max_new_tokens + 1, b, dtype=torch.int64, device=dev)
+        self.step_idx = torch.zeros((), dtype=torch.int64, device=dev)
+        self.max_new_tokens = max_new_tokens
+        self.steps_done = 0
+        cfg = runner.cfg
+        h = cfg.num_attention_heads // runner.world_size
+        ops.reserve_workspace(dev, ops.decode_workspace_bytes(b, h, cfg.head_dim, self.block_tables.shape[1], bs))
+        self.graph = None
+        if use_graph:
+            self._capture()
+
+    def _advance(self, next_tokens):
+        """Device-side postprocess + prepare_decode for the following step."""
+        bs = self.runner.block_size
+        self.tokens.index_copy_(0, self.step_idx.view(1), next_tokens.view(1, -1))    # capturable (no host read of step_idx)
+        self.step_idx += 1
+        self.input_ids.copy_(next_tokens)
+        self.positions += 1
+        self.context_lens += 1
+        last = (self.context_lens - 1).long()
+        blk = torch.gather(self.block_tables, 1, (last // bs).unsqueeze(1)).squeeze(1)
+        self.slot_mapping.copy_((blk.long() * bs + last % bs).int())
+
+    def _step(self):
+        set_context(False, slot_mapping=self.slot_mapping, context_lens=self.context_lens, block_tables=self.block_tables)
+        hidden = self.runner.model(self.input_ids, self.positions)
+        self._advance(self.runner.model.compute_logits(hidden).argmax(dim=-1))
+        reset_context()
+
+    @torch.inference_mode()
+    def _capture(self):
+        # capture must not disturb the live state: snapshot, warm up + capture, restore
+        saved = [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx)]
+        stream = torch.cuda.Stream(device=self.runner.device)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            self._step()                                      # warm-up on the side stream (allocator, hipBLASLt heuristics)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        self.step_idx.zero_()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self._step()
+        for t, s in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx), saved):
+            t.copy_(s)
+        # the KV rows the warm-up/capture steps wrote lie beyond the live context and are overwritten by real steps
+
+    @torch.inference_mode()
+    def step(self, n=1):
+        assert self.steps_done + n <= self.max_new_tokens
+        for _ in range(n):
+            if self.graph is not None:
+                self.graph.replay()
+            else:
+                self._step()
+        self.steps_done += n
+
+    def rewind(self, seqs_state):
+        """Reset the device metadata to a saved state (benchmark use: time the same context window repeatedly)."""
+        for t, s in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx), seqs_state):
+            t.copy_(s)
+        self.steps_done = int(self.step_idx.item())
+
+    def state(self):
+        return [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx)]
+
+    def finish(self):
+        """Copy generated tokens back into the host sequences (one device->host sync for the whole generation)."""
+        toks = self.tokens[: self.steps_done].cpu().tolist()
+        for row in toks:
+            for s, t in zip(self.seqs, row):
+                s.append_token(int(t))
+        return toks

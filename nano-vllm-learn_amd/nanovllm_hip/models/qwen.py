@@ -1,0 +1,213 @@
+"""Qwen2 / Qwen3 decoder bodies on PyTorch-ROCm, just enough to drive the attention path end to end.
+
+Only the attention op is this package's product; everything else here (GEMMs through hipBLASLt, norms,
+RoPE, SwiGLU) is plumbing that mirrors the reference model so the attention module is called exactly the
+way nanovllm/models/qwen3.py calls it:
+  * backend dispatch by string (qwen3.py:44-56) through nanovllm_hip.resolve_attention
+  * positional construction `Attention(num_heads, head_dim, scale, num_kv_heads, **kw)` (qwen3.py:89-95)
+  * qkv_proj -> split -> (per-head q/k RMSNorm, Qwen3 only) -> RoPE -> attn(q, k, v) -> o_proj (qwen3.py:99-119);
+    v reaches the attention module as a strided view of the fused qkv output
+  * tensor parallel = head split (qwen3.py:30-39) with an all-reduce after o_proj and down_proj
+    (layers/linear.py:185-190); embedding and LM head are kept replicated (a simplification: every rank
+    computes the same greedy token, so no gather is needed).
+Weights are random (N(0, 0.02), seed fixed): the container has no checkpoints and no network.
+The reference hard-codes Qwen3 (model_runner.py:37); Qwen2 shapes (BASELINE.json) need bias on qkv and no
+q/k norm, which `qk_norm=False, qkv_bias=True` selects.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from ..config import resolve_attention
+
+
+@dataclass
+class ModelConfig:
+    name: str
+    num_hidden_layers: int
+    hidden_size: int
+    num_attention_heads: int
+    num_key_value_heads: int
+    head_dim: int
+    intermediate_size: int
+    vocab_size: int
+    tie_word_embeddings: bool
+    qkv_bias: bool
+    qk_norm: bool
+    rope_theta: float = 1000000.0
+    rms_norm_eps: float = 1e-6
+    max_position_embeddings: int = 32768
+    attn_backend: str = "hip"
+    kvcache_block_size: int = 256
+
+
+# public HF config.json values
+SHAPES = {
+    "Qwen2-0.5B": dict(num_hidden_layers=24, hidden_size=896, num_attention_heads=14, num_key_value_heads=2, head_dim=64,
+                       intermediate_size=4864, vocab_size=151936, tie_word_embeddings=True, qkv_bias=True, qk_norm=False),
+    "Qwen2-7B": dict(num_hidden_layers=28, hidden_size=3584, num_attention_heads=28, num_key_value_heads=4, head_dim=128,
+                     intermediate_size=18944, vocab_size=152064, tie_word_embeddings=False, qkv_bias=True, qk_norm=False),
+    "Qwen3-0.6B": dict(num_hidden_layers=28, hidden_size=1024, num_attention_heads=16, num_key_value_heads=8, head_dim=128,
+                       intermediate_size=3072, vocab_size=151936, tie_word_embeddings=True, qkv_bias=False, qk_norm=True),
+}
+
+
+def model_config(name: str, **overrides) -> ModelConfig:
+    return ModelConfig(name=name, **{**SHAPES[name], **overrides})
+
+
+def _tp():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, size, eps):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(size))
+
+    def forward(self, x):
+        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
+
+
+class RotaryEmbedding(nn.Module):
+    """Neox-style RoPE with a precomputed cos/sin table, fp32 math (layers/rotary_embedding.py:6-55)."""
+
+    def __init__(self, head_dim, max_position, base):
+        super().__init__()
+        inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+        freqs = torch.outer(torch.arange(max_position, dtype=torch.float), inv_freq)
+        self.register_buffer("cos_sin", torch.cat((freqs.cos(), freqs.sin()), dim=-1), persistent=False)
+        self.head_dim = head_dim
+
+    def _rot(self, x, cos, sin):
+        x1, x2 = torch.chunk(x.float(), 2, dim=-1)
+        return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1).to(x.dtype)
+
+    def forward(self, positions, q, k):
+        cos, sin = self.cos_sin[positions].float().unsqueeze(-2).chunk(2, dim=-1)
+        n = positions.shape[0]
+        q = self._rot(q.view(n, -1, self.head_dim), cos, sin).view(q.shape)
+        k = self._rot(k.view(n, -1, self.head_dim), cos, sin).view(k.shape)
+        return q, k
+
+
+class QwenAttention(nn.Module):
+    def __init__(self, cfg: ModelConfig):
+        super().__init__()
+        _, tp = _tp()
+        assert cfg.num_attention_heads % tp == 0 and cfg.num_key_value_heads % tp == 0     # qwen3.py:32,35
+        self.num_heads = cfg.num_attention_heads // tp
+        self.num_kv_heads = cfg.num_key_value_heads // tp
+        self.head_dim = cfg.head_dim
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.scaling = self.head_dim ** -0.5
+        attn_cls, attn_kwargs = resolve_attention(cfg.attn_backend, cfg.kvcache_block_size)       # qwen3.py:44-56
+        self.qkv_proj = nn.Linear(cfg.hidden_size, self.q_size + 2 * self.kv_size, bias=cfg.qkv_bias)
+        self.o_proj = nn.Linear(self.q_size, cfg.hidden_size, bias=False)
+        self.rotary_emb = RotaryEmbedding(self.head_dim, cfg.max_position_embeddings, cfg.rope_theta)
+        self.attn = attn_cls(self.num_heads, self.head_dim, self.scaling, self.num_kv_heads, **attn_kwargs)   # qwen3.py:89-95
+        self.qk_norm = cfg.qk_norm
+        if cfg.qk_norm:
+            self.q_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps)
+            self.k_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps)
+
+    def forward(self, positions, hidden_states):
+        qkv = self.qkv_proj(hidden_states)
+        q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
+        if self.qk_norm:
+            q = self.q_norm(q.reshape(-1, self.num_heads, self.head_dim)).view(-1, self.q_size)
+            k = self.k_norm(k.reshape(-1, self.num_kv_heads, self.head_dim)).view(-1, self.kv_size)
+        q, k = self.rotary_emb(positions, q, k)
+        o = self.attn(q, k, v)                                   # qwen3.py:117 — the hot path
+        out = self.o_proj(o)
+        if _tp()[1] > 1:
+            dist.all_reduce(out)                                 # layers/linear.py:188-189 (RCCL over xGMI)
+        return out
+
+
+class QwenMLP(nn.Module):
+    def __init__(self, cfg: ModelConfig):
+        super().__init__()
+        _, tp = _tp()
+        assert cfg.intermediate_size % tp == 0
+        inter = cfg.intermediate_size // tp
+        self.gate_up_proj = nn.Linear(cfg.hidden_size, 2 * inter, bias=False)
+        self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
+
+    def forward(self, x):
+        gate, up = self.gate_up_proj(x).chunk(2, dim=-1)
+        out = self.down_proj(F.silu(gate) * up)
+        if _tp()[1] > 1:
+            dist.all_reduce(out)
+        return out
+
+
+class QwenDecoderLayer(nn.Module):
+    def __init__(self, cfg: ModelConfig):
+        super().__init__()
+        self.self_attn = QwenAttention(cfg)
+        self.mlp = QwenMLP(cfg)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+    def forward(self, positions, hidden_states):
+        hidden_states = hidden_states + self.self_attn(positions, self.input_layernorm(hidden_states))
+        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+
+
+class QwenForCausalLM(nn.Module):
+    def __init__(self, cfg: ModelConfig):
+        super().__init__()
+        self.cfg = cfg
+        self.embed_tokens = nn.Embedding(cfg.vocab_size, cfg.hidden_size)
+        self.layers = nn.ModuleList([QwenDecoderLayer(cfg) for _ in range(cfg.num_hidden_layers)])
+        self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        if not cfg.tie_word_embeddings:
+            self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
+
+    def forward(self, input_ids, positions):
+        h = self.embed_tokens(input_ids)
+        for layer in self.layers:
+            h = layer(positions, h)
+        return self.norm(h)
+
+    def compute_logits(self, hidden_states):
+        w = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight
+        return F.linear(hidden_states, w)
+
+    @torch.no_grad()
+    def init_random(self, seed=0):
+        """Deterministic N(0, 0.02) weights; every rank draws the full tensors and keeps its shard so that
+        tp=N equals tp=1 on the same seed."""
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        rank, tp = _tp()
+        cfg = self.cfg
+
+        def draw(*shape):
+            return torch.randn(*shape, generator=gen) * 0.02
+
+        def shard_rows(full, parts):                               # column-parallel: split output rows per part
+            return torch.cat([p.chunk(tp, dim=0)[rank] for p in parts(full)], dim=0)
+
+        self.embed_tokens.weight.copy_(draw(cfg.vocab_size, cfg.hidden_size))
+        if not cfg.tie_word_embeddings:
+            self.lm_head.weight.copy_(draw(cfg.vocab_size, cfg.hidden_size))
+        hq, hkv, d = cfg.num_attention_heads * cfg.head_dim, cfg.num_key_value_heads * cfg.head_dim, cfg.head_dim
+        for layer in self.layers:
+            a, m = layer.self_attn, layer.mlp
+            a.qkv_proj.weight.copy_(shard_rows(draw(hq + 2 * hkv, cfg.hidden_size), lambda w: w.split([hq, hkv, hkv], dim=0)))
+            if cfg.qkv_bias:
+                a.qkv_proj.bias.copy_(shard_rows(draw(hq + 2 * hkv), lambda w: w.split([hq, hkv, hkv], dim=0)))
+            a.o_proj.weight.copy_(draw(cfg.hidden_size, hq).chunk(tp, dim=1)[rank])
+            m.gate_up_proj.weight.copy_(shard_rows(draw(2 * cfg.intermediate_size, cfg.hidden_size), lambda w: w.chunk(2, dim=0)))
+            m.down_proj.weight.copy_(draw(cfg.hidden_size, cfg.intermediate_size).chunk(tp, dim=1)[rank])
+        return self

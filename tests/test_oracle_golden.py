@@ -107,3 +107,16 @@ def test_bf16_roundtrip_helpers():
     assert np.array_equal(O.round_to_bf16(r), r)
     assert np.all(np.abs(r - x) <= np.abs(x) * 2.0 ** -8)
     assert O.f32_to_bf16_bits(np.array([1.00390625], np.float32))[0] == 0x3F80   # tie -> even
+
+
+@pytest.mark.parametrize("name", DECODE)
+def test_sdpa_math_cpu_port_matches_reference(golden, name):
+    """The torch port timed as `cpu_baseline` (oracle/sdpa_math_cpu.py) equals the reference's output."""
+    import torch
+    from oracle.sdpa_math_cpu import flash_attn_with_kvcache_cpu
+    g = golden(name)
+    q = torch.from_numpy(O.bf16_bits_to_f32(g["q"])).unsqueeze(1)
+    out = flash_attn_with_kvcache_cpu(q, torch.from_numpy(O.bf16_bits_to_f32(g["k_cache"])),
+                                      torch.from_numpy(O.bf16_bits_to_f32(g["v_cache"])),
+                                      torch.from_numpy(g["context_lens"]), torch.from_numpy(g["block_tables"]))
+    assert np.abs(out[:, 0].numpy() - g["expected"]).max() <= TOL
