@@ -126,6 +126,23 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                        int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream);
 
+/*
+ * "Next" row: the step immediately before attention, fused into one launch.
+ * (optional per-head RMSNorm ->) neox RoPE on q and k IN PLACE inside the fused qkv projection output, then
+ * k (rotated) and v rows are stored to the paged cache.
+ * Replaces: q_norm/k_norm (nanovllm/models/qwen3.py:108-114, layers/layernorm.py:17-27), rotary_emb
+ *           (layers/rotary_embedding.py:39-55) and store_kvcache (layers/attention.py:84-86).
+ *   qkv            [n_tokens, (h + 2*kvh) * hd] bf16, row stride qkv_row_stride (elements): q heads | k heads | v heads
+ *   positions      int64 [n_tokens]; cos_sin fp32 [max_position, hd] = cos(0..hd/2) | sin(0..hd/2)
+ *                  (the reference's cos_sin_cache, rotary_embedding.py:29-36)
+ *   q_norm_w/k_norm_w  bf16 [hd] or NULL (both or neither); eps as in RMSNorm
+ *   k_cache/v_cache/slot_mapping  as nvh_store_kvcache; NULL caches or slot < 0 -> no store for that row
+ */
+int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,
+                   const void* q_norm_w, const void* k_norm_w, float eps,
+                   void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                   int n_tokens, int h, int kvh, int hd, int64_t qkv_row_stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

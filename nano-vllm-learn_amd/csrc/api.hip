@@ -209,4 +209,31 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
     return launch_prefill_varlen(a, (hipStream_t)stream);
 }
 
+int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,
+                   const void* q_norm_w, const void* k_norm_w, float eps,
+                   void* k_cache, void* v_cache, const int32_t* slot_mapping,
+                   int n_tokens, int h, int kvh, int hd, int64_t qkv_row_stride, int dtype, void* stream) {
+    if (n_tokens == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("rope_store: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!qkv || !positions || !cos_sin) { set_error("rope_store: null pointer"); return NVH_E_NULL; }
+    if ((q_norm_w == nullptr) != (k_norm_w == nullptr)) { set_error("rope_store: q_norm_w and k_norm_w must both be set or both be NULL"); return NVH_E_NULL; }
+    if ((k_cache == nullptr) != (v_cache == nullptr)) { set_error("rope_store: k_cache and v_cache must both be set or both be NULL"); return NVH_E_NULL; }
+    if (n_tokens < 0 || h <= 0 || kvh <= 0 || (hd != 64 && hd != 128)) { set_error("rope_store: bad shape h=%d kvh=%d hd=%d", h, kvh, hd); return NVH_E_SHAPE; }
+    if (qkv_row_stride % 8 || qkv_row_stride < (int64_t)(h + 2 * kvh) * hd) {
+        set_error("rope_store: qkv row stride %lld", (long long)qkv_row_stride);
+        return NVH_E_STRIDE;
+    }
+    if (!aligned16(qkv) || !aligned16(cos_sin) || (k_cache && (!aligned16(k_cache) || !aligned16(v_cache))) ||
+        (q_norm_w && (!aligned16(q_norm_w) || !aligned16(k_norm_w)))) {
+        set_error("rope_store: pointers must be 16-byte aligned");
+        return NVH_E_ALIGN;
+    }
+    RopeStoreArgs a;
+    a.qkv = (uint16_t*)qkv; a.positions = positions; a.cos_sin = cos_sin;
+    a.q_norm_w = (const uint16_t*)q_norm_w; a.k_norm_w = (const uint16_t*)k_norm_w; a.eps = eps;
+    a.k_cache = (uint16_t*)k_cache; a.v_cache = (uint16_t*)v_cache; a.slot_mapping = slot_mapping;
+    a.n_tokens = n_tokens; a.h = h; a.kvh = kvh; a.hd = hd; a.qkv_row_stride = qkv_row_stride;
+    return launch_rope_store(a, (hipStream_t)stream);
+}
+
 }  // extern "C"

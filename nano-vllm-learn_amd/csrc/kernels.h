@@ -30,6 +30,21 @@ struct DecodeArgs {
 int decode_split_tokens(int hd);
 int launch_paged_decode(const DecodeArgs& a, hipStream_t stream);
 
+struct RopeStoreArgs {
+    uint16_t* qkv;               // [N, (H+2KVH)*D] fused projection output, rotated in place
+    const int64_t* positions;    // [N]
+    const float* cos_sin;        // [max_position, D]: cos(0..D/2) | sin(0..D/2)
+    const uint16_t* q_norm_w;    // [D] or null (no per-head RMSNorm)
+    const uint16_t* k_norm_w;
+    float eps;
+    uint16_t* k_cache;           // nullable: no store
+    uint16_t* v_cache;
+    const int32_t* slot_mapping; // nullable
+    int n_tokens, h, kvh, hd;
+    int64_t qkv_row_stride;
+};
+int launch_rope_store(const RopeStoreArgs& a, hipStream_t stream);
+
 struct PrefillArgs {
     void* out;                   // [Tq, H, D]
     const uint16_t* q;           // [Tq, H, D], row stride q_row_stride

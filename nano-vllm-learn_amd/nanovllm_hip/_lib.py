@@ -29,6 +29,8 @@ _SIGS = {
                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nvh_prefill_varlen": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_i32p] * 3 + [ctypes.c_int] * 8 +
                            [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "nvh_rope_store": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_float] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 +
+                       [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

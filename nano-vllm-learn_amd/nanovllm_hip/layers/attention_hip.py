@@ -26,14 +26,27 @@ class Attention(nn.Module):
         self.fused_decode = fused_decode        # one C-ABI call for store + attend on the decode step
         self.k_cache = self.v_cache = torch.tensor([])
 
+    def rope_store_attend(self, qkv, positions, cos_sin, q_norm_weight=None, k_norm_weight=None, eps=1e-6):
+        """Widened entry: takes the fused projection output, applies (q/k norm ->) RoPE and the
+        cache store in ONE launch (nvh_rope_store), then attends without a second store.  Same result as
+        q_norm/k_norm + rotary_emb + forward(q, k, v) of the reference call sequence (qwen3.py:104-117)."""
+        context = get_context()
+        h, kvh, d = self.num_heads, self.num_kv_heads, self.head_dim
+        ops.rope_store(qkv, positions, cos_sin, h, kvh, d, self.k_cache, self.v_cache, context.slot_mapping,
+                       q_norm_weight, k_norm_weight, eps)
+        q, k, v = qkv.split([h * d, kvh * d, kvh * d], dim=-1)
+        return self._attend(q.view(-1, h, d), k.view(-1, kvh, d), v.view(-1, kvh, d), context, store=False)
+
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
         q = q.view(-1, self.num_heads, self.head_dim)
         k = k.view(-1, self.num_kv_heads, self.head_dim)
         v = v.view(-1, self.num_kv_heads, self.head_dim)
-        context = get_context()
+        return self._attend(q, k, v, get_context(), store=True)
+
+    def _attend(self, q, k, v, context, store):
         k_cache, v_cache = self.k_cache, self.v_cache
         have_cache = k_cache.numel() > 0 and v_cache.numel() > 0       # warmup prefill runs before allocation
-        store = have_cache and context.slot_mapping is not None        # attention.py:84, attention_sdpa.py:242
+        store = store and have_cache and context.slot_mapping is not None   # attention.py:84, attention_sdpa.py:242
 
         if context.is_prefill:
             if store:

@@ -77,22 +77,36 @@ class RMSNorm(nn.Module):
         return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
 
 
+_COS_SIN = {}
+
+
+def cos_sin_table(head_dim, max_position, base, device):
+    """fp32 [max_position, head_dim] = cos | sin, one copy per device shared by all layers
+    (the reference's cos_sin_cache, layers/rotary_embedding.py:29-36; kept fp32 regardless of the model dtype)."""
+    key = (head_dim, max_position, float(base), str(device))
+    if key not in _COS_SIN:
+        inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
+        freqs = torch.outer(torch.arange(max_position, dtype=torch.float), inv_freq)
+        _COS_SIN[key] = torch.cat((freqs.cos(), freqs.sin()), dim=-1).to(device)
+    return _COS_SIN[key]
+
+
 class RotaryEmbedding(nn.Module):
     """Neox-style RoPE with a precomputed cos/sin table, fp32 math (layers/rotary_embedding.py:6-55)."""
 
     def __init__(self, head_dim, max_position, base):
         super().__init__()
-        inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float) / head_dim))
-        freqs = torch.outer(torch.arange(max_position, dtype=torch.float), inv_freq)
-        self.register_buffer("cos_sin", torch.cat((freqs.cos(), freqs.sin()), dim=-1), persistent=False)
-        self.head_dim = head_dim
+        self.head_dim, self.max_position, self.base = head_dim, max_position, base
+
+    def table(self, device):
+        return cos_sin_table(self.head_dim, self.max_position, self.base, device)
 
     def _rot(self, x, cos, sin):
         x1, x2 = torch.chunk(x.float(), 2, dim=-1)
         return torch.cat((x1 * cos - x2 * sin, x2 * cos + x1 * sin), dim=-1).to(x.dtype)
 
     def forward(self, positions, q, k):
-        cos, sin = self.cos_sin[positions].float().unsqueeze(-2).chunk(2, dim=-1)
+        cos, sin = self.table(q.device)[positions].unsqueeze(-2).chunk(2, dim=-1)
         n = positions.shape[0]
         q = self._rot(q.view(n, -1, self.head_dim), cos, sin).view(q.shape)
         k = self._rot(k.view(n, -1, self.head_dim), cos, sin).view(k.shape)
@@ -122,6 +136,14 @@ class QwenAttention(nn.Module):
 
     def forward(self, positions, hidden_states):
         qkv = self.qkv_proj(hidden_states)
+        if hasattr(self.attn, "rope_store_attend"):              # hip backend: norm -> RoPE -> store fused into one launch
+            o = self.attn.rope_store_attend(qkv, positions, self.rotary_emb.table(qkv.device),
+                                            self.q_norm.weight if self.qk_norm else None,
+                                            self.k_norm.weight if self.qk_norm else None, self.q_norm.eps if self.qk_norm else 1e-6)
+            out = self.o_proj(o)
+            if _tp()[1] > 1:
+                dist.all_reduce(out)
+            return out
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         if self.qk_norm:
             q = self.q_norm(q.reshape(-1, self.num_heads, self.head_dim)).view(-1, self.q_size)

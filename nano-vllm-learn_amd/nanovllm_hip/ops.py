@@ -189,3 +189,31 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
                                         NVH_BF16, _out_code(out.dtype), _stream())
     _lib.check(rc, "nvh_prefill_varlen")
     return out
+
+
+# --------------------------------------------------------------------------------------- rope + store (next row f2)
+def rope_store(qkv, positions, cos_sin, num_heads, num_kv_heads, head_dim, k_cache=None, v_cache=None, slot_mapping=None,
+               q_norm_weight=None, k_norm_weight=None, eps=1e-6):
+    """In-place (optional per-head RMSNorm ->) neox RoPE on the q and k parts of the fused projection output
+    `qkv` [N, (H+2KVH)*D], then k/v rows -> paged cache at slot_mapping (skipped when no cache is bound or slot < 0).
+    Equivalent to q_norm/k_norm + rotary_emb + store_kvcache of the reference (qwen3.py:108-116, attention.py:84-86)."""
+    _require_gpu_bf16(qkv=qkv)
+    n = qkv.shape[0]
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.shape[1] == (num_heads + 2 * num_kv_heads) * head_dim
+    assert positions.dtype == torch.int64 and positions.is_cuda and positions.numel() == n and positions.is_contiguous()
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_cuda and cos_sin.is_contiguous() and cos_sin.shape[1] == head_dim
+    have_cache = k_cache is not None and k_cache.numel() > 0 and slot_mapping is not None
+    if have_cache:
+        _require_gpu_bf16(k_cache=k_cache, v_cache=v_cache)
+        _require_i32(slot_mapping=slot_mapping)
+        assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.stride(1) == num_kv_heads * head_dim
+        assert slot_mapping.numel() == n and slot_mapping.is_contiguous()
+    if q_norm_weight is not None:
+        _require_gpu_bf16(q_norm_weight=q_norm_weight, k_norm_weight=k_norm_weight)
+    rc = _lib.load().nvh_rope_store(qkv.data_ptr(), positions.data_ptr(), cos_sin.data_ptr(),
+                                    q_norm_weight.data_ptr() if q_norm_weight is not None else None,
+                                    k_norm_weight.data_ptr() if k_norm_weight is not None else None, float(eps),
+                                    k_cache.data_ptr() if have_cache else None, v_cache.data_ptr() if have_cache else None,
+                                    slot_mapping.data_ptr() if have_cache else None,
+                                    n, num_heads, num_kv_heads, head_dim, qkv.stride(0), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_rope_store")

@@ -165,6 +165,21 @@ def gen_meta(name):
     print(name, "keys", len(out))
 
 
+def gen_rope(name, seed, heads, D, n_tokens, base=1000000.0, max_position=4096):
+    """nanovllm.layers.rotary_embedding: RotaryEmbedding.__init__ builds cos_sin_cache (:29-36, plain code) and
+    apply_rotary_emb (:6-16, plain function) rotates; forward itself is @torch.compile'd and is not called."""
+    from nanovllm.layers.rotary_embedding import RotaryEmbedding, apply_rotary_emb
+    gen = torch.Generator().manual_seed(seed)
+    rope = RotaryEmbedding(D, D, max_position, base)
+    x = randn_bf16(gen, n_tokens, heads, D).to(torch.bfloat16)
+    pos = torch.randint(0, max_position, (n_tokens,), generator=gen)
+    cos, sin = rope.cos_sin_cache[pos].chunk(2, dim=-1)
+    y = apply_rotary_emb(x, cos, sin)
+    np.savez_compressed(os.path.join(OUT, name), x=bf16_bits(x), positions=pos.numpy(), expected=bf16_bits(y),
+                        cos_sin=rope.cos_sin_cache.float().numpy()[:64], shape=np.array([heads, D, max_position]), base=np.array([base]))
+    print(name, "tokens", n_tokens)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -181,6 +196,9 @@ def main():
     # (3) store
     gen_store("store_d64.npz", 21, 2, 64, 61, 4)
     gen_store("store_d128.npz", 22, 1, 128, 40, 3)
+    # (3b) RoPE (the step before attention)
+    gen_rope("rope_d64.npz", 31, 16, 64, 37)
+    gen_rope("rope_d128.npz", 32, 5, 128, 19)
     # (4) runner metadata
     gen_meta("meta_runner.npz")
 

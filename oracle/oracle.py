@@ -33,7 +33,9 @@ from __future__ import annotations
 
 import numpy as np
 
+# (rope_neox / rms_norm_heads below restate the step just before attention: SURVEY.md section 8f row 2)
 __all__ = [
+    "rope_cos_sin", "rope_neox", "rms_norm_heads",
     "bf16_bits_to_f32", "f32_to_bf16_bits", "round_to_bf16",
     "store_kvcache", "paged_decode", "prefill_varlen", "paged_prefill",
     "prepare_block_tables", "prepare_decode", "prepare_prefill", "SeqState",
@@ -279,3 +281,33 @@ def prepare_prefill(seqs):
                 cu_seqlens_q=np.array(cu_q, dtype=np.int32), cu_seqlens_k=np.array(cu_k, dtype=np.int32),
                 max_seqlen_q=max_q, max_seqlen_k=max_k,
                 slot_mapping=np.array(slots, dtype=np.int32), block_tables=block_tables)
+
+
+# --------------------------------------------------------------------------- f2: (q/k norm ->) RoPE, the step before attention
+def rope_cos_sin(head_dim, max_position, base):
+    """fp32 table [max_position, head_dim] = cos | sin  (layers/rotary_embedding.py:29-36)."""
+    inv_freq = (1.0 / (np.float32(base) ** (np.arange(0, head_dim, 2, dtype=np.float32) / np.float32(head_dim)))).astype(np.float32)
+    freqs = np.outer(np.arange(max_position, dtype=np.float32), inv_freq).astype(np.float32)
+    return np.concatenate([np.cos(freqs), np.sin(freqs)], axis=-1).astype(np.float32)
+
+
+def rope_neox(x, positions, cos_sin):
+    """apply_rotary_emb (layers/rotary_embedding.py:6-16): x [N, heads, D] (bf16-valued); fp32 products and sums
+    rounded separately, result rounded to bf16 (returned as bf16-valued float32)."""
+    x = np.asarray(x, dtype=np.float32)
+    d = x.shape[-1]
+    cs = cos_sin[np.asarray(positions)]
+    cos, sin = cs[:, None, : d // 2], cs[:, None, d // 2:]
+    x1, x2 = x[..., : d // 2], x[..., d // 2:]
+    y1 = (x1 * cos).astype(np.float32) - (x2 * sin).astype(np.float32)
+    y2 = (x2 * cos).astype(np.float32) + (x1 * sin).astype(np.float32)
+    return round_to_bf16(np.concatenate([y1, y2], axis=-1).astype(np.float32))
+
+
+def rms_norm_heads(x, weight, eps):
+    """RMSNorm.rms_forward (layers/layernorm.py:17-27) over the last dim: fp32 normalise, round to bf16, multiply
+    by the bf16 weight in bf16."""
+    x = np.asarray(x, dtype=np.float32)
+    var = np.mean(x.astype(np.float64) ** 2, axis=-1, keepdims=True)
+    normed = round_to_bf16((x * (1.0 / np.sqrt(var + eps))).astype(np.float32))
+    return round_to_bf16((normed * np.asarray(weight, dtype=np.float32)).astype(np.float32))

@@ -120,3 +120,21 @@ def test_sdpa_math_cpu_port_matches_reference(golden, name):
                                       torch.from_numpy(O.bf16_bits_to_f32(g["v_cache"])),
                                       torch.from_numpy(g["context_lens"]), torch.from_numpy(g["block_tables"]))
     assert np.abs(out[:, 0].numpy() - g["expected"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", ["rope_d64.npz", "rope_d128.npz"])
+def test_rope_restatement_matches_reference(golden, name):
+    """oracle.rope_neox / rope_cos_sin against the reference's apply_rotary_emb + cos_sin_cache (bit-exact bf16)."""
+    g = golden(name)
+    heads, d, max_pos = (int(x) for x in g["shape"])
+    import torch
+    base = float(g["base"][0])
+    # the reference's table, built with the same torch ops as rotary_embedding.py:29-36
+    inv_freq = 1.0 / (base ** (torch.arange(0, d, 2, dtype=torch.float) / d))
+    freqs = torch.einsum("i,j -> ij", torch.arange(max_pos, dtype=torch.float), inv_freq)
+    table = torch.cat((freqs.cos(), freqs.sin()), dim=-1).numpy()
+    assert np.array_equal(table[:64], g["cos_sin"])
+    got = O.rope_neox(O.bf16_bits_to_f32(g["x"]), g["positions"], table)
+    assert np.array_equal(got, O.bf16_bits_to_f32(g["expected"]))                 # bit-exact
+    # the pure-numpy table agrees to fp32 argument-reduction accuracy (pos * inv_freq in fp32 at positions up to 4096)
+    assert np.abs(O.rope_cos_sin(d, max_pos, base) - table).max() <= 5e-4
