@@ -23,11 +23,14 @@ HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "nvh_att
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-Wall", "-Wno-unused-function", "-Wno-unused-command-line-argument"]
+# rope_store.hip must round RoPE's products and sums separately (bit parity with the reference's elementwise fp32 ops);
+# HIP's default backend contraction ignores the source pragma, so that file is built with contraction off.
+FILE_FLAGS = {"rope_store.hip": ["-ffp-contract=off"]}
 
 
 def _digest():
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     for name in SOURCES + HEADERS:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(f.read())
@@ -36,10 +39,11 @@ def _digest():
 
 def _compile(src, asm):
     obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-    cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+    flags = [*FLAGS, *FILE_FLAGS.get(src, [])]
+    cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.run(cmd, check=True)
     if asm:
-        subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+        subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
                         os.path.join(CSRC, src), "-o", obj.replace(".o", ".s")], check=False,
                        stderr=open(obj.replace(".o", ".resources.txt"), "w"))
     return obj

@@ -19,6 +19,10 @@
 #include "common.h"
 #include "kernels.h"
 
+// The whole file: no fused multiply-add contraction.  RoPE products and sums must round separately to match the
+// reference's elementwise fp32 ops bit for bit (an exact bf16 tie flipped under -ffp-contract=fast).
+#pragma clang fp contract(off)
+
 namespace nvh {
 
 namespace {
@@ -70,7 +74,6 @@ __global__ __launch_bounds__(256) void rope_store_kernel(const RopeStoreArgs a) 
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(cs + D / 2), s1 = *reinterpret_cast<const f32x4*>(cs + D / 2 + 4);
             float y1[8], y2[8];
             {
-#pragma clang fp contract(off)   // products and sums rounded separately, as the reference's elementwise ops do
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float co = e < 4 ? c0[e] : c1[e - 4], si = e < 4 ? s0[e] : s1[e - 4];
