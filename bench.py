@@ -53,7 +53,10 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     between calls), replayed `iters` times between two HIP events on the launching stream."""
     from nanovllm_hip import ops
     dev = torch.device("cuda", torch.cuda.current_device())
-    h, kvh, d, bs = cfg.num_attention_heads // tp, max(cfg.num_key_value_heads // tp, 1), cfg.head_dim, cfg.kvcache_block_size
+    from nanovllm_hip.models.qwen import tp_partition
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    _, h, _, kvh = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
+    d, bs = cfg.head_dim, cfg.kvcache_block_size
     nblk = (ctx + bs - 1) // bs
     nb = batch * nblk + 1
     gen = torch.Generator(device="cpu").manual_seed(0)
@@ -90,7 +93,7 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     torch.cuda.synchronize()
     us = start.elapsed_time(end) * 1e3 / (iters * layers)
     nbytes = decode_attn_bytes([ctx] * batch, h, kvh, d, bs)
-    return us, nbytes
+    return us, nbytes, (h, kvh, d)
 
 
 def cpu_baseline_leg(cfg, batch, ctx, budget_s=12.0):
@@ -196,12 +199,11 @@ def main():
     # ---- roofline leg: the attention op alone at the mean context of the timed window
     mean_ctx = ctx0 + (args.steps - 1) // 2
     tp = world
-    attn_us, attn_bytes = attention_leg(cfg, tp, args.batch, mean_ctx, cfg.num_hidden_layers)
+    attn_us, attn_bytes, shape_rank = attention_leg(cfg, tp, args.batch, mean_ctx, cfg.num_hidden_layers)
     achieved = attn_bytes / attn_us / 1e3                              # GB/s
 
     result = None
     if rank == 0:
-        kvh_r = max(cfg.num_key_value_heads // tp, 1)
         weight_bytes = sum(p.numel() * p.element_size() for p in engine.runner.model.parameters())
         step_bytes = weight_bytes + cfg.num_hidden_layers * attn_bytes
         step_us = elapsed / args.steps * 1e6
@@ -218,7 +220,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                          "kernel": "nvh_decode_step = store_kvcache + paged_decode_split_mfma + paged_decode_combine (one attention call)",
                          "bytes_per_launch": attn_bytes, "us_per_launch": round(attn_us, 2), "context": mean_ctx,
-                         "shape_per_rank": [cfg.num_attention_heads // tp, kvh_r, cfg.head_dim]},
+                         "shape_per_rank": list(shape_rank)},
             "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),
                                      "frac": round(step_bytes / 8e6 / step_us, 4),
                                      "attention_share_of_step": round(cfg.num_hidden_layers * attn_us / step_us, 3)},

@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 
 from .. import ops
-from ..models.qwen import ModelConfig, QwenForCausalLM
+from ..models.qwen import ModelConfig, QwenForCausalLM, tp_partition
 from ..utils.context import reset_context, set_context
 from .sequence import Sequence
 
@@ -83,7 +83,7 @@ class ModelRunner:
 
     def allocate_kv_cache(self):
         cfg = self.cfg
-        kvh = cfg.num_key_value_heads // self.world_size
+        kvh = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, self.world_size, self.rank)[3]
         self.kv_cache = torch.zeros(2, cfg.num_hidden_layers, self.num_kvcache_blocks, self.block_size, kvh, cfg.head_dim,
                                     dtype=torch.bfloat16, device=self.device)
         layer_id = 0
@@ -146,7 +146,7 @@ class DecodeSession:
         self.max_new_tokens = max_new_tokens
         self.steps_done = 0
         cfg = runner.cfg
-        h = cfg.num_attention_heads // runner.world_size
+        h = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, runner.world_size, runner.rank)[1]
         ops.reserve_workspace(dev, ops.decode_workspace_bytes(b, h, cfg.head_dim, self.block_tables.shape[1], bs))
         self.graph = None
         if use_graph:

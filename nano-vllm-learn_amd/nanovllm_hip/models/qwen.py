@@ -67,6 +67,26 @@ def _tp():
     return 0, 1
 
 
+def tp_partition(num_heads, num_kv_heads, tp, rank):
+    """Head ranges of one tensor-parallel rank: (q_start, q_count, kv_start, kv_count).
+
+    The reference splits both head counts evenly and asserts divisibility (models/qwen3.py:30-36).  When that holds
+    this is exactly its split.  When tp exceeds what the kv heads allow (Qwen2-0.5B: 14/2 heads at tp=4/8, Qwen2-7B:
+    28/4 at tp=8) every kv head is REPLICATED on tp/KVH ranks and the G = H/KVH query heads that
+    share it are divided among those ranks as evenly as possible (sizes differ by at most one).  Each q head still
+    attends exactly its own kv head and o_proj is row-sliced by the same q heads, so the summed result is unchanged;
+    it departs from the reference only in lifting its divisibility assert."""
+    if num_heads % tp == 0 and num_kv_heads % tp == 0:
+        return rank * (num_heads // tp), num_heads // tp, rank * (num_kv_heads // tp), num_kv_heads // tp
+    assert tp % num_kv_heads == 0, f"tp={tp} must be a multiple of num_kv_heads={num_kv_heads} when it does not divide it"
+    per_kv = tp // num_kv_heads                      # ranks sharing one kv head
+    group = num_heads // num_kv_heads
+    assert group >= per_kv, f"group of {group} q heads cannot be split over {per_kv} ranks"
+    kv, sub = rank // per_kv, rank % per_kv
+    base, extra = divmod(group, per_kv)
+    return kv * group + sub * base + min(sub, extra), base + (sub < extra), kv, 1
+
+
 class RMSNorm(nn.Module):
     def __init__(self, size, eps):
         super().__init__()
@@ -116,10 +136,8 @@ class RotaryEmbedding(nn.Module):
 class QwenAttention(nn.Module):
     def __init__(self, cfg: ModelConfig):
         super().__init__()
-        _, tp = _tp()
-        assert cfg.num_attention_heads % tp == 0 and cfg.num_key_value_heads % tp == 0     # qwen3.py:32,35
-        self.num_heads = cfg.num_attention_heads // tp
-        self.num_kv_heads = cfg.num_key_value_heads // tp
+        rank, tp = _tp()
+        _, self.num_heads, _, self.num_kv_heads = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
         self.head_dim = cfg.head_dim
         self.q_size = self.num_heads * self.head_dim
         self.kv_size = self.num_kv_heads * self.head_dim
@@ -220,16 +238,22 @@ class QwenForCausalLM(nn.Module):
         def shard_rows(full, parts):                               # column-parallel: split output rows per part
             return torch.cat([p.chunk(tp, dim=0)[rank] for p in parts(full)], dim=0)
 
+        q0, qn, kv0, kvn = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
+
+        def shard_qkv(full):                                       # rows of this rank's q heads | kv heads | kv heads
+            wq, wk, wv = full.split([hq, hkv, hkv], dim=0)
+            return torch.cat([wq[q0 * d:(q0 + qn) * d], wk[kv0 * d:(kv0 + kvn) * d], wv[kv0 * d:(kv0 + kvn) * d]], dim=0)
+
         self.embed_tokens.weight.copy_(draw(cfg.vocab_size, cfg.hidden_size))
         if not cfg.tie_word_embeddings:
             self.lm_head.weight.copy_(draw(cfg.vocab_size, cfg.hidden_size))
         hq, hkv, d = cfg.num_attention_heads * cfg.head_dim, cfg.num_key_value_heads * cfg.head_dim, cfg.head_dim
         for layer in self.layers:
             a, m = layer.self_attn, layer.mlp
-            a.qkv_proj.weight.copy_(shard_rows(draw(hq + 2 * hkv, cfg.hidden_size), lambda w: w.split([hq, hkv, hkv], dim=0)))
+            a.qkv_proj.weight.copy_(shard_qkv(draw(hq + 2 * hkv, cfg.hidden_size)))
             if cfg.qkv_bias:
-                a.qkv_proj.bias.copy_(shard_rows(draw(hq + 2 * hkv), lambda w: w.split([hq, hkv, hkv], dim=0)))
-            a.o_proj.weight.copy_(draw(cfg.hidden_size, hq).chunk(tp, dim=1)[rank])
+                a.qkv_proj.bias.copy_(shard_qkv(draw(hq + 2 * hkv)))
+            a.o_proj.weight.copy_(draw(cfg.hidden_size, hq)[:, q0 * d:(q0 + qn) * d])
             m.gate_up_proj.weight.copy_(shard_rows(draw(2 * cfg.intermediate_size, cfg.hidden_size), lambda w: w.chunk(2, dim=0)))
             m.down_proj.weight.copy_(draw(cfg.hidden_size, cfg.intermediate_size).chunk(tp, dim=1)[rank])
         return self
