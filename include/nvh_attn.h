@@ -143,6 +143,19 @@ int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,
                    void* k_cache, void* v_cache, const int32_t* slot_mapping,
                    int n_tokens, int h, int kvh, int hd, int64_t qkv_row_stride, int dtype, void* stream);
 
+/*
+ * Engine widening (not part of the attention parity bar): the row-wise elementwise ops either side of the attention
+ * block, one launch each instead of 5-6 eager launches per layer.
+ *   nvh_add_rmsnorm  RMSNorm.forward(x[, residual]), nanovllm/layers/layernorm.py:17-50: if `residual` is non-NULL it is
+ *                    updated in place to bf16(x + residual) and the norm is taken of the fp32 sum; out = norm * weight.
+ *                    x/out/residual [n_rows, hidden] bf16 with row strides in elements; hidden % 8 == 0, hidden <= 8192.
+ *   nvh_silu_mul     SiluAndMul.forward, nanovllm/layers/activation.py:11-14: out[:, i] = silu(gu[:, i]) * gu[:, inter + i].
+ */
+int nvh_add_rmsnorm(void* out, const void* x, void* residual, const void* weight, float eps, int n_rows, int hidden,
+                    int64_t x_row_stride, int64_t out_row_stride, int64_t residual_row_stride, int dtype, void* stream);
+int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gate_up_row_stride, int64_t out_row_stride,
+                 int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -236,4 +236,32 @@ int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,
     return launch_rope_store(a, (hipStream_t)stream);
 }
 
+int nvh_add_rmsnorm(void* out, const void* x, void* residual, const void* weight, float eps, int n_rows, int hidden,
+                    int64_t x_row_stride, int64_t out_row_stride, int64_t residual_row_stride, int dtype, void* stream) {
+    if (n_rows == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("add_rmsnorm: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!out || !x || !weight) { set_error("add_rmsnorm: null pointer"); return NVH_E_NULL; }
+    if (n_rows < 0 || hidden <= 0 || hidden % 8 || hidden > max_rmsnorm_hidden()) { set_error("add_rmsnorm: hidden %d unsupported", hidden); return NVH_E_SHAPE; }
+    if (x_row_stride % 8 || out_row_stride % 8 || (residual && residual_row_stride % 8) || x_row_stride < hidden || out_row_stride < hidden) {
+        set_error("add_rmsnorm: row strides must be multiples of 8 and >= hidden");
+        return NVH_E_STRIDE;
+    }
+    if (!aligned16(out) || !aligned16(x) || !aligned16(weight) || (residual && !aligned16(residual))) { set_error("add_rmsnorm: pointers must be 16-byte aligned"); return NVH_E_ALIGN; }
+    return launch_add_rmsnorm(out, x, residual, weight, eps, n_rows, hidden, x_row_stride, out_row_stride, residual_row_stride, (hipStream_t)stream);
+}
+
+int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gate_up_row_stride, int64_t out_row_stride,
+                 int dtype, void* stream) {
+    if (n_rows == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("silu_mul: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!out || !gate_up) { set_error("silu_mul: null pointer"); return NVH_E_NULL; }
+    if (n_rows < 0 || inter <= 0 || inter % 8) { set_error("silu_mul: inter %d must be a positive multiple of 8", inter); return NVH_E_SHAPE; }
+    if (gate_up_row_stride % 8 || out_row_stride % 8 || gate_up_row_stride < 2 * (int64_t)inter || out_row_stride < inter) {
+        set_error("silu_mul: bad row strides");
+        return NVH_E_STRIDE;
+    }
+    if (!aligned16(out) || !aligned16(gate_up)) { set_error("silu_mul: pointers must be 16-byte aligned"); return NVH_E_ALIGN; }
+    return launch_silu_mul(out, gate_up, n_rows, inter, gate_up_row_stride, out_row_stride, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -45,6 +45,11 @@ struct RopeStoreArgs {
 };
 int launch_rope_store(const RopeStoreArgs& a, hipStream_t stream);
 
+int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, float eps, int n_rows, int hidden,
+                       int64_t x_stride, int64_t out_stride, int64_t res_stride, hipStream_t stream);
+int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream);
+int max_rmsnorm_hidden(void);
+
 struct PrefillArgs {
     void* out;                   // [Tq, H, D]
     const uint16_t* q;           // [Tq, H, D], row stride q_row_stride

@@ -1,0 +1,127 @@
+// Row-wise fused elementwise ops around the attention call (engine widening; not part of the attention parity bar):
+//   add_rmsnorm  residual-add + RMSNorm in one launch   — nanovllm/layers/layernorm.py:17-41 (rms_forward / add_rms_forward)
+//   silu_mul     SiLU(gate) * up                          — nanovllm/layers/activation.py:11-14
+// Both are HBM-bound row streams (2-3 x rows x hidden x 2 bytes); at decode they are launch-latency bound, which is
+// exactly why they are fused: eager PyTorch spends 5-6 launches per layer on them.  One workgroup per row, 16-byte
+// accesses, fp32 math with the reference's rounding points:
+//   x32 = float(x) + float(residual); residual_out = bf16(x32); var = mean(x32^2);
+//   out = bf16( float(bf16(x32 * rsqrt(var + eps))) * float(weight) )          (layernorm.py:35-40)
+#include "common.h"
+#include "kernels.h"
+
+namespace nvh {
+
+namespace {
+
+constexpr int ROW_THREADS = 256;
+constexpr int MAX_CHUNKS = 4;                 // 16-byte chunks per thread: hidden <= 256*4*8 = 8192
+
+__device__ __forceinline__ float block_sum(float v, float* lds) {
+    v += pair_in_row<1>(v);
+    v += pair_in_row<2>(v);
+    v += pair_in_row<4>(v);
+    v += pair_in_row<8>(v);
+    v = sum_xor16(v);
+    v = sum_xor32(v);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wave] = v;
+    __syncthreads();
+    return lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+// out = rmsnorm(x [+ residual]) * w ; residual (in/out, nullable) receives bf16(x + residual)
+__global__ __launch_bounds__(ROW_THREADS) void add_rmsnorm_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ x,
+                                                                   uint16_t* __restrict__ residual, const uint16_t* __restrict__ w,
+                                                                   float eps, int hidden, int64_t x_stride, int64_t out_stride, int64_t res_stride) {
+    __shared__ float lds[4];
+    const int row = blockIdx.x;
+    const int chunks = hidden / 8;
+    const uint16_t* xr = x + row * x_stride;
+    uint16_t* rr = residual ? residual + row * res_stride : nullptr;
+    float v[MAX_CHUNKS][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAX_CHUNKS; ++i) {
+        const int c = threadIdx.x + i * ROW_THREADS;
+        if (c < chunks) {
+            const u32x4 xv = *reinterpret_cast<const u32x4*>(xr + c * 8);
+            u32x4 rv = {0, 0, 0, 0};
+            if (rr) rv = *reinterpret_cast<const u32x4*>(rr + c * 8);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[i][2 * k] = bf16_lo(xv[k]) + (rr ? bf16_lo(rv[k]) : 0.f);
+                v[i][2 * k + 1] = bf16_hi(xv[k]) + (rr ? bf16_hi(rv[k]) : 0.f);
+            }
+            if (rr) {
+                u32x4 ro;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) ro[k] = pack_bf16x2(v[i][2 * k], v[i][2 * k + 1]);
+                *reinterpret_cast<u32x4*>(rr + c * 8) = ro;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ss += v[i][k] * v[i][k];
+        }
+    }
+    const float inv = rsqrtf(block_sum(ss, lds) / hidden + eps);
+#pragma unroll
+    for (int i = 0; i < MAX_CHUNKS; ++i) {
+        const int c = threadIdx.x + i * ROW_THREADS;
+        if (c < chunks) {
+            const u32x4 wv = *reinterpret_cast<const u32x4*>(w + c * 8);
+            u32x4 ov;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = (float)(__bf16)(v[i][2 * k] * inv) * bf16_lo(wv[k]);
+                const float b = (float)(__bf16)(v[i][2 * k + 1] * inv) * bf16_hi(wv[k]);
+                ov[k] = pack_bf16x2(a, b);
+            }
+            *reinterpret_cast<u32x4*>(out + row * out_stride + c * 8) = ov;
+        }
+    }
+}
+
+// out[row, 0:inter] = silu(gu[row, 0:inter]) * gu[row, inter:2*inter]
+__global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ out, const uint16_t* __restrict__ gu, int n_rows, int inter,
+                                                        int64_t gu_stride, int64_t out_stride) {
+    const int chunks = inter / 8;
+    const int64_t total = (int64_t)n_rows * chunks;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / chunks), c = (int)(idx - (int64_t)row * chunks);
+        const uint16_t* g = gu + row * gu_stride + c * 8;
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(g);
+        const u32x4 uv = *reinterpret_cast<const u32x4*>(g + inter);
+        u32x4 ov;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float g0 = bf16_lo(gv[k]), g1 = bf16_hi(gv[k]);
+            // F.silu on bf16 computes in fp32 and rounds to bf16; the product with `up` rounds again
+            const float s0 = (float)(__bf16)(g0 / (1.f + __expf(-g0))), s1 = (float)(__bf16)(g1 / (1.f + __expf(-g1)));
+            ov[k] = pack_bf16x2(s0 * bf16_lo(uv[k]), s1 * bf16_hi(uv[k]));
+        }
+        *reinterpret_cast<u32x4*>(out + row * out_stride + c * 8) = ov;
+    }
+}
+
+}  // namespace
+
+int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, float eps, int n_rows, int hidden,
+                       int64_t x_stride, int64_t out_stride, int64_t res_stride, hipStream_t stream) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(add_rmsnorm_kernel, dim3(n_rows), dim3(ROW_THREADS), 0, stream, (uint16_t*)out, (const uint16_t*)x,
+                       (uint16_t*)residual, (const uint16_t*)w, eps, hidden, x_stride, out_stride, res_stride);
+    return check_launch("add_rmsnorm");
+}
+
+int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream) {
+    if (n_rows == 0) return 0;
+    const int64_t total = (int64_t)n_rows * (inter / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(blocks), dim3(256), 0, stream, (uint16_t*)out, (const uint16_t*)gate_up, n_rows, inter,
+                       gu_stride, out_stride);
+    return check_launch("silu_mul");
+}
+
+int max_rmsnorm_hidden(void) { return ROW_THREADS * MAX_CHUNKS * 8; }
+
+}  // namespace nvh

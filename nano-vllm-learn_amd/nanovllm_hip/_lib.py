@@ -31,6 +31,9 @@ _SIGS = {
                            [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "nvh_rope_store": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_float] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 +
                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "nvh_add_rmsnorm": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
+                        [ctypes.c_int, ctypes.c_void_p]),
+    "nvh_silu_mul": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -88,13 +88,36 @@ def tp_partition(num_heads, num_kv_heads, tp, rank):
 
 
 class RMSNorm(nn.Module):
+    """RMSNorm with the reference's optional fused residual add (layers/layernorm.py:43-50): forward(x) -> y, or
+    forward(x, residual) -> (y, x + residual).  On the GPU it is one HIP launch (nvh_add_rmsnorm); the torch form below
+    has the same rounding points and serves CPU-side tests of the model plumbing."""
+
     def __init__(self, size, eps):
         super().__init__()
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(size))
 
-    def forward(self, x):
-        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
+    def forward(self, x, residual=None):
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 8192:
+            from .. import ops
+            if residual is None:
+                return ops.add_rmsnorm(x, self.weight, self.eps)
+            return ops.add_rmsnorm(x, self.weight, self.eps, residual), residual        # residual updated in place
+        x32 = x.float()
+        if residual is not None:
+            x32 = x32 + residual.float()
+            residual = x32.to(x.dtype)
+        y = (x32 * torch.rsqrt(x32.pow(2).mean(dim=-1, keepdim=True) + self.eps)).to(x.dtype) * self.weight
+        return y if residual is None else (y, residual)
+
+
+def silu_and_mul(gate_up):
+    """SiluAndMul (layers/activation.py:11-14); one HIP launch on the GPU."""
+    if gate_up.is_cuda and gate_up.dtype == torch.bfloat16 and gate_up.shape[-1] % 16 == 0:
+        from .. import ops
+        return ops.silu_mul(gate_up)
+    gate, up = gate_up.chunk(2, dim=-1)
+    return F.silu(gate) * up
 
 
 _COS_SIN = {}
@@ -164,8 +187,8 @@ class QwenAttention(nn.Module):
             return out
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         if self.qk_norm:
-            q = self.q_norm(q.reshape(-1, self.num_heads, self.head_dim)).view(-1, self.q_size)
-            k = self.k_norm(k.reshape(-1, self.num_kv_heads, self.head_dim)).view(-1, self.kv_size)
+            q = self.q_norm(q.reshape(-1, self.num_heads, self.head_dim).contiguous()).view(-1, self.q_size)
+            k = self.k_norm(k.reshape(-1, self.num_kv_heads, self.head_dim).contiguous()).view(-1, self.kv_size)
         q, k = self.rotary_emb(positions, q, k)
         o = self.attn(q, k, v)                                   # qwen3.py:117 — the hot path
         out = self.o_proj(o)
@@ -184,8 +207,7 @@ class QwenMLP(nn.Module):
         self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
 
     def forward(self, x):
-        gate, up = self.gate_up_proj(x).chunk(2, dim=-1)
-        out = self.down_proj(F.silu(gate) * up)
+        out = self.down_proj(silu_and_mul(self.gate_up_proj(x)))
         if _tp()[1] > 1:
             dist.all_reduce(out)
         return out
@@ -199,9 +221,16 @@ class QwenDecoderLayer(nn.Module):
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
 
-    def forward(self, positions, hidden_states):
-        hidden_states = hidden_states + self.self_attn(positions, self.input_layernorm(hidden_states))
-        return hidden_states + self.mlp(self.post_attention_layernorm(hidden_states))
+    def forward(self, positions, hidden_states, residual):
+        # the reference's residual flow (models/qwen3.py:179-193): every norm also performs the pending residual add
+        if residual is None:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+        else:
+            hidden_states, residual = self.input_layernorm(hidden_states, residual)
+        hidden_states = self.self_attn(positions, hidden_states)
+        hidden_states, residual = self.post_attention_layernorm(hidden_states, residual)
+        return self.mlp(hidden_states), residual
 
 
 class QwenForCausalLM(nn.Module):
@@ -215,10 +244,11 @@ class QwenForCausalLM(nn.Module):
             self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
 
     def forward(self, input_ids, positions):
-        h = self.embed_tokens(input_ids)
+        h, residual = self.embed_tokens(input_ids), None
         for layer in self.layers:
-            h = layer(positions, h)
-        return self.norm(h)
+            h, residual = layer(positions, h, residual)
+        h, _ = self.norm(h, residual)
+        return h
 
     def compute_logits(self, hidden_states):
         w = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight

@@ -217,3 +217,35 @@ def rope_store(qkv, positions, cos_sin, num_heads, num_kv_heads, head_dim, k_cac
                                     slot_mapping.data_ptr() if have_cache else None,
                                     n, num_heads, num_kv_heads, head_dim, qkv.stride(0), NVH_BF16, _stream())
     _lib.check(rc, "nvh_rope_store")
+
+
+# --------------------------------------------------------------------------------------- row-wise ops around the attention block
+def add_rmsnorm(x, weight, eps, residual=None):
+    """RMSNorm.forward(x[, residual]) of the reference (layernorm.py:43-50) in one launch.  `residual`, when given, is
+    updated IN PLACE to x + residual (bf16) and the norm is taken of the fp32 sum.  Returns the normalised tensor."""
+    _require_gpu_bf16(x=x, weight=weight)
+    hidden = x.shape[-1]
+    x2 = x.view(-1, hidden)
+    assert x2.stride(1) == 1 and weight.numel() == hidden and weight.is_contiguous()
+    out = torch.empty((x2.shape[0], hidden), dtype=torch.bfloat16, device=x.device)
+    r2 = None
+    if residual is not None:
+        _require_gpu_bf16(residual=residual)
+        r2 = residual.view(-1, hidden)
+        assert r2.shape == x2.shape and r2.stride(1) == 1
+    rc = _lib.load().nvh_add_rmsnorm(out.data_ptr(), x2.data_ptr(), r2.data_ptr() if r2 is not None else None, weight.data_ptr(), float(eps),
+                                     x2.shape[0], hidden, x2.stride(0), out.stride(0), r2.stride(0) if r2 is not None else 0, NVH_BF16, _stream())
+    _lib.check(rc, "nvh_add_rmsnorm")
+    return out.view(x.shape)
+
+
+def silu_mul(gate_up):
+    """SiluAndMul.forward (activation.py:11-14): silu(gate_up[..., :I]) * gate_up[..., I:]."""
+    _require_gpu_bf16(gate_up=gate_up)
+    inter = gate_up.shape[-1] // 2
+    g2 = gate_up.view(-1, 2 * inter)
+    assert g2.stride(1) == 1
+    out = torch.empty((g2.shape[0], inter), dtype=torch.bfloat16, device=gate_up.device)
+    rc = _lib.load().nvh_silu_mul(out.data_ptr(), g2.data_ptr(), g2.shape[0], inter, g2.stride(0), out.stride(0), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_silu_mul")
+    return out.view(*gate_up.shape[:-1], inter)
