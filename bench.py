@@ -96,6 +96,20 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     return us, nbytes, (h, kvh, d)
 
 
+def pmc_traffic(cfg, tp, batch, ctx):
+    """HBM bytes per attention call from the committed rocprofv3 PMC passes (profiles/r01_pmc_decode_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE), attached only when the profiled workload is this one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_decode_traffic.json")
+    try:
+        p = json.load(open(path))
+    except OSError:
+        return None
+    w = p["workload"]
+    same = (tp == 1 and w["batch"] == batch and w["ctx"] == ctx and w["heads"] == cfg.num_attention_heads and
+            w["kv_heads"] == cfg.num_key_value_heads and w["head_dim"] == cfg.head_dim)
+    return p["hbm_bytes_per_attention_call"] if same else None
+
+
 def cpu_baseline_leg(cfg, batch, ctx, budget_s=12.0):
     """Time the CPU port of the reference's sdpa.math decode call (one layer, bf16 like the reference) on the host."""
     from oracle.sdpa_math_cpu import flash_attn_with_kvcache_cpu
@@ -214,11 +228,11 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random prompts randint(0,10000) seed 0; random-init weights N(0,0.02) seed 0)",
             "config": {"workload": f"{args.model} bs={args.batch} in={args.input_len} decode steps={args.steps} --attn-backend hip, "
-                                   f"TP={tp}, HIP-graph replay, device-resident metadata",
+                                   f"TP={tp}, {'HIP-graph replay' if sess.graph is not None else 'eager steps (graph capture unavailable)'}, device-resident metadata",
                        "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                         "kernel": "nvh_decode_step = store_kvcache + paged_decode_split_mfma + paged_decode_combine (one attention call)",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(cfg, tp, args.batch, mean_ctx),
+                         "kernel": "one decode attention call = paged_decode_split_mfma (dominant) + paged_decode_combine (+ store_kvcache in this leg)",
                          "bytes_per_launch": attn_bytes, "us_per_launch": round(attn_us, 2), "context": mean_ctx,
                          "shape_per_rank": list(shape_rank)},
             "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),

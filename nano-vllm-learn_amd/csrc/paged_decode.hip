@@ -47,7 +47,7 @@ namespace {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         if (a.stamps && lane == 0)                                                                       \
-            a.stamps[(((int64_t)b * gridDim.y + kh) * gridDim.x + split) * (WAVES * 8) + wave * 8 + (k)] = t_; \
+            a.stamps[(((int64_t)b * a.kvh + kh) * a.num_splits + split) * (WAVES * 8) + wave * 8 + (k)] = t_; \
     } while (0)
 #else
 #define NVH_STAMP(k) do {} while (0)
@@ -287,7 +287,9 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
     unsigned char* const lds_q = lds + MW * geo::WAVE_BYTES;
     float* const lds_ml = reinterpret_cast<float*>(lds_q + QI * 1024);              // [wave][max | sum][16 heads]
 
-    const int split = blockIdx.x, kh = blockIdx.y, b = blockIdx.z;
+    // grid (KVH*B, num_splits): workgroups are dispatched x-fastest, so every sequence's split 0 goes first and the
+    // splits past the live contexts (graph replay uses a fixed-width block table) are dispatched last and retire at once
+    const int split = blockIdx.y, kh = blockIdx.x % a.kvh, b = blockIdx.x / a.kvh;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,7 +529,7 @@ int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
 
 template <int D>
 int launch_mfma(const DecodeArgs& a, int g, hipStream_t stream) {
-    dim3 grid(a.num_splits, a.kvh, a.batch);
+    dim3 grid(a.kvh * a.batch, a.num_splits);
     hipLaunchKernelGGL((paged_decode_split_mfma_kernel<D>), grid, dim3(MW * 64), 0, stream, a, g);
     int rc = check_launch("paged_decode_split_mfma");
     return rc ? rc : launch_combine<D>(a, stream);

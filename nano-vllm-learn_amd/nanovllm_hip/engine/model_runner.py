@@ -150,7 +150,13 @@ class DecodeSession:
         ops.reserve_workspace(dev, ops.decode_workspace_bytes(b, h, cfg.head_dim, self.block_tables.shape[1], bs))
         self.graph = None
         if use_graph:
-            self._capture()
+            try:
+                self._capture()
+            except Exception as e:                            # e.g. a collective that cannot be captured on this stack
+                import warnings
+                warnings.warn(f"HIP-graph capture of the decode step failed ({type(e).__name__}: {e}); running eager steps")
+                self.graph = None
+                torch.cuda.synchronize()
 
     def _advance(self, next_tokens):
         """Device-side postprocess + prepare_decode for the following step."""
@@ -173,19 +179,23 @@ class DecodeSession:
     @torch.inference_mode()
     def _capture(self):
         # capture must not disturb the live state: snapshot, warm up + capture, restore
-        saved = [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx)]
-        stream = torch.cuda.Stream(device=self.runner.device)
-        stream.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(stream):
-            self._step()                                      # warm-up on the side stream (allocator, hipBLASLt heuristics)
-        torch.cuda.current_stream().wait_stream(stream)
-        torch.cuda.synchronize()
-        self.step_idx.zero_()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self._step()
-        for t, s in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx), saved):
-            t.copy_(s)
+        live = (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx)
+        saved = [t.clone() for t in live]
+        try:
+            stream = torch.cuda.Stream(device=self.runner.device)
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                self._step()                                  # warm-up on the side stream (allocator, hipBLASLt heuristics)
+            torch.cuda.current_stream().wait_stream(stream)
+            torch.cuda.synchronize()
+            self.step_idx.zero_()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step()
+            self.graph = graph
+        finally:
+            for t, s in zip(live, saved):
+                t.copy_(s)
         # the KV rows the warm-up/capture steps wrote lie beyond the live context and are overwritten by real steps
 
     @torch.inference_mode()
