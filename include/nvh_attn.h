@@ -156,6 +156,19 @@ int nvh_add_rmsnorm(void* out, const void* x, void* residual, const void* weight
 int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gate_up_row_stride, int64_t out_row_stride,
                  int dtype, void* stream);
 
+/*
+ * Engine widening: weight-streaming linear layer for decode-sized batches, out = x . W^T (+ bias), m <= 64 rows.
+ * Replaces F.linear in nanovllm/layers/linear.py:55-190 at decode (the hipBLASLt path stays for larger m).
+ *   x [m, k] bf16 (row stride in elements); w [n, k] bf16 contiguous (nn.Linear layout); bias [n] bf16 or NULL
+ *   silu_inter == 0 : out [m, n] = x w^T + bias
+ *   silu_inter  > 0 : n == 2*silu_inter, rows [0, inter) of w are gate_proj and [inter, 2*inter) up_proj
+ *                     (MergedColumnParallelLinear, linear.py:90-111); out [m, inter] = SiLU(x gate^T) * (x up^T), i.e. the
+ *                     projection and layers/activation.py:11-14 in one launch; bias must be NULL.
+ *   k % 32 == 0, n % 16 == 0 (and inter % 16 == 0).
+ */
+int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias, int m, int n, int k, int silu_inter,
+                       int64_t x_row_stride, int64_t out_row_stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -264,4 +264,20 @@ int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t 
     return launch_silu_mul(out, gate_up, n_rows, inter, gate_up_row_stride, out_row_stride, (hipStream_t)stream);
 }
 
+int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias, int m, int n, int k, int silu_inter,
+                       int64_t x_row_stride, int64_t out_row_stride, int dtype, void* stream) {
+    if (m == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("linear_small_m: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!out || !x || !w) { set_error("linear_small_m: null pointer"); return NVH_E_NULL; }
+    if (m < 0 || m > 64 || n <= 0 || k <= 0 || k % 32 || n % 16) { set_error("linear_small_m: m=%d (<=64) n=%d (%%16) k=%d (%%32)", m, n, k); return NVH_E_SHAPE; }
+    if (silu_inter && (silu_inter * 2 != n || silu_inter % 16 || bias)) { set_error("linear_small_m: silu mode needs n == 2*inter, inter %% 16 == 0, no bias"); return NVH_E_SHAPE; }
+    const int out_cols = silu_inter ? silu_inter : n;
+    if (x_row_stride % 8 || x_row_stride < k || out_row_stride < out_cols) { set_error("linear_small_m: bad row strides"); return NVH_E_STRIDE; }
+    if (!aligned16(x) || !aligned16(w)) { set_error("linear_small_m: x and w must be 16-byte aligned"); return NVH_E_ALIGN; }
+    LinearArgs a;
+    a.out = out; a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.bias = (const uint16_t*)bias;
+    a.M = m; a.N = n; a.K = k; a.inter = silu_inter; a.x_stride = x_row_stride; a.out_stride = out_row_stride;
+    return launch_linear_small_m(a, (hipStream_t)stream);
+}
+
 }  // extern "C"

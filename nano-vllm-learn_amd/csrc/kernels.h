@@ -50,6 +50,17 @@ int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, 
 int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream);
 int max_rmsnorm_hidden(void);
 
+struct LinearArgs {
+    void* out;                   // [M, N] bf16 (SILU mode: [M, inter])
+    const uint16_t* x;           // [M, K] bf16, row stride x_stride
+    const uint16_t* w;           // [N, K] bf16 contiguous (nn.Linear layout)
+    const uint16_t* bias;        // [N] bf16 or null
+    int M, N, K;
+    int inter;                   // > 0: SiLU(gate)*up epilogue, N == 2*inter, gate rows [0, inter), up rows [inter, 2*inter)
+    int64_t x_stride, out_stride;
+};
+int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
+
 struct PrefillArgs {
     void* out;                   // [Tq, H, D]
     const uint16_t* q;           // [Tq, H, D], row stride q_row_stride

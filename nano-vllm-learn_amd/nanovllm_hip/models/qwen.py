@@ -111,6 +111,15 @@ class RMSNorm(nn.Module):
         return y if residual is None else (y, residual)
 
 
+def linear(x, weight, bias=None):
+    """F.linear; decode-sized batches on the GPU take the weight-streaming HIP kernel (ops.linear_small_m), anything
+    else (prefill, CPU tests) goes to the vendor GEMM."""
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] <= 64 and x.shape[-1] % 32 == 0 and weight.shape[0] % 16 == 0:
+        from .. import ops
+        return ops.linear_small_m(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
 def silu_and_mul(gate_up):
     """SiluAndMul (layers/activation.py:11-14); one HIP launch on the GPU."""
     if gate_up.is_cuda and gate_up.dtype == torch.bfloat16 and gate_up.shape[-1] % 16 == 0:
@@ -176,12 +185,12 @@ class QwenAttention(nn.Module):
             self.k_norm = RMSNorm(self.head_dim, cfg.rms_norm_eps)
 
     def forward(self, positions, hidden_states):
-        qkv = self.qkv_proj(hidden_states)
+        qkv = linear(hidden_states, self.qkv_proj.weight, self.qkv_proj.bias)
         if hasattr(self.attn, "rope_store_attend"):              # hip backend: norm -> RoPE -> store fused into one launch
             o = self.attn.rope_store_attend(qkv, positions, self.rotary_emb.table(qkv.device),
                                             self.q_norm.weight if self.qk_norm else None,
                                             self.k_norm.weight if self.qk_norm else None, self.q_norm.eps if self.qk_norm else 1e-6)
-            out = self.o_proj(o)
+            out = linear(o, self.o_proj.weight)
             if _tp()[1] > 1:
                 dist.all_reduce(out)
             return out
@@ -191,7 +200,7 @@ class QwenAttention(nn.Module):
             k = self.k_norm(k.reshape(-1, self.num_kv_heads, self.head_dim).contiguous()).view(-1, self.kv_size)
         q, k = self.rotary_emb(positions, q, k)
         o = self.attn(q, k, v)                                   # qwen3.py:117 — the hot path
-        out = self.o_proj(o)
+        out = linear(o, self.o_proj.weight)
         if _tp()[1] > 1:
             dist.all_reduce(out)                                 # layers/linear.py:188-189 (RCCL over xGMI)
         return out
@@ -207,7 +216,13 @@ class QwenMLP(nn.Module):
         self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
 
     def forward(self, x):
-        out = self.down_proj(silu_and_mul(self.gate_up_proj(x)))
+        w = self.gate_up_proj.weight
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] <= 64 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0:
+            from .. import ops
+            act = ops.linear_small_m(x, w, silu_mul=True)         # gate_up projection + SiLU*mul in one launch
+        else:
+            act = silu_and_mul(F.linear(x, w))
+        out = linear(act, self.down_proj.weight)
         if _tp()[1] > 1:
             dist.all_reduce(out)
         return out
@@ -252,7 +267,7 @@ class QwenForCausalLM(nn.Module):
 
     def compute_logits(self, hidden_states):
         w = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight
-        return F.linear(hidden_states, w)
+        return linear(hidden_states, w)
 
     @torch.no_grad()
     def init_random(self, seed=0):

@@ -249,3 +249,25 @@ def silu_mul(gate_up):
     rc = _lib.load().nvh_silu_mul(out.data_ptr(), g2.data_ptr(), g2.shape[0], inter, g2.stride(0), out.stride(0), NVH_BF16, _stream())
     _lib.check(rc, "nvh_silu_mul")
     return out.view(*gate_up.shape[:-1], inter)
+
+
+LINEAR_SMALL_M_MAX = 64
+
+
+def linear_small_m(x, weight, bias=None, silu_mul=False):
+    """F.linear(x, weight, bias) for at most 64 rows, streaming `weight` [N, K] once; with silu_mul=True `weight` is the
+    merged gate_up projection and the result is SiLU(x gate^T) * (x up^T) (projection + activation.py:11-14 in one launch)."""
+    _require_gpu_bf16(x=x, weight=weight)
+    k = x.shape[-1]
+    x2 = x.view(-1, k)
+    n = weight.shape[0]
+    assert x2.shape[0] <= LINEAR_SMALL_M_MAX and x2.stride(1) == 1 and weight.is_contiguous() and weight.shape[1] == k
+    inter = n // 2 if silu_mul else 0
+    out = torch.empty((x2.shape[0], inter if silu_mul else n), dtype=torch.bfloat16, device=x.device)
+    if bias is not None:
+        _require_gpu_bf16(bias=bias)
+        assert bias.numel() == n and bias.is_contiguous()
+    rc = _lib.load().nvh_linear_small_m(out.data_ptr(), x2.data_ptr(), weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                        x2.shape[0], n, k, inter, x2.stride(0), out.stride(0), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_linear_small_m")
+    return out.view(*x.shape[:-1], out.shape[1])

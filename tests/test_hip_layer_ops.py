@@ -66,3 +66,36 @@ def test_engine_greedy_tokens_graph_equals_eager():
         outs.append(eng.generate(prompts, max_tokens=13))
     assert outs[0] == outs[1]
     assert all(len(o) == 13 for o in outs[0])
+
+
+@pytest.mark.parametrize("m,n,k,bias", [(32, 1152, 896, True), (32, 896, 896, False), (32, 896, 4864, False), (1, 1024, 1024, False),
+                                         (64, 576, 3584, True), (17, 151936, 896, False), (48, 32, 64, True)])
+def test_linear_small_m(m, n, k, bias):
+    """out = x W^T + b against an fp32 reference of the same bf16 operands (fp32 accumulate, one rounding)."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(m + n + k)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(n, generator=g).bfloat16().cuda() if bias else None
+    ref = torch.nn.functional.linear(x.float(), w.float(), b.float() if bias else None)
+    out = ops.linear_small_m(x, w, b)
+    torch.cuda.synchronize()
+    err = (out.float() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 2e-3).all(), err.max()          # one bf16 rounding of the fp32 result (+ summation-order slack)
+
+
+@pytest.mark.parametrize("m,inter,k", [(32, 4864, 896), (5, 608, 896), (64, 1536, 1024)])
+def test_linear_small_m_silu(m, inter, k):
+    """gate_up projection + SiluAndMul in one launch == F.linear -> bf16 -> silu*mul (activation.py:11-14)."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(inter + k)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(2 * inter, k, generator=g) * 0.05).bfloat16().cuda()
+    gu = torch.nn.functional.linear(x.float(), w.float()).bfloat16()
+    ref = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+    out = ops.linear_small_m(x, w, silu_mul=True)
+    torch.cuda.synchronize()
+    err = (out.float() - ref.float()).abs()
+    # the fused kernel rounds the same fp32 sums to bf16; summation order can flip a rounding of gate or up (<= 1 ulp each)
+    assert (err <= 2.0 ** -6 * ref.float().abs() + 2e-3).all(), err.max()
+    assert (err > 2.0 ** -8 * ref.float().abs() + 1e-4).float().mean() < 0.05
