@@ -164,10 +164,45 @@ int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t 
  *   silu_inter  > 0 : n == 2*silu_inter, rows [0, inter) of w are gate_proj and [inter, 2*inter) up_proj
  *                     (MergedColumnParallelLinear, linear.py:90-111); out [m, inter] = SiLU(x gate^T) * (x up^T), i.e. the
  *                     projection and layers/activation.py:11-14 in one launch; bias must be NULL.
- *   k % 32 == 0, n % 16 == 0 (and inter % 16 == 0).
+ *   k % 64 == 0, n % 16 == 0 (and inter % 16 == 0).
  */
 int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias, int m, int n, int k, int silu_inter,
                        int64_t x_row_stride, int64_t out_row_stride, int dtype, void* stream);
+
+/*
+ * The same weight-streaming product with the neighbouring row-wise ops of a decoder layer fused in, so that a decode
+ * layer is 6 launches (qkv, attention split, attention combine, o_proj, gate_up, down) instead of 10:
+ *   norm_weight != NULL : prologue x := RMSNorm(x) * norm_weight   (RMSNorm.rms_forward, nanovllm/layers/layernorm.py:17-27)
+ *   epilogue NVH_EPI_NONE          out [m, n] = product + bias
+ *            NVH_EPI_SILU_MUL      as nvh_linear_small_m with silu_inter
+ *            NVH_EPI_RESIDUAL_ADD  out is the residual stream [m, n]: out += product, in place (the add of
+ *                                  add_rms_forward, layernorm.py:35-36, done by the producing GEMM instead of the consuming norm)
+ *            NVH_EPI_ROPE_STORE    n == (h + 2*kvh) * hd (fused qkv projection, models/qwen3.py:104-106): + bias, neox RoPE on
+ *                                  the q and k heads, q -> out [m, h*hd]; k and v rows -> k_cache / v_cache at slot_mapping[row]
+ *                                  (slot < 0: skipped).  Same arithmetic and rounding points as nvh_rope_store; no q/k norm.
+ */
+#define NVH_EPI_NONE          0
+#define NVH_EPI_SILU_MUL      1
+#define NVH_EPI_RESIDUAL_ADD  2
+#define NVH_EPI_ROPE_STORE    3
+typedef struct nvh_linear_desc {
+    void* out;
+    const void* x;
+    const void* w;
+    const void* bias;               /* NULL or [n] */
+    int32_t m, n, k, silu_inter;
+    int64_t x_row_stride, out_row_stride;
+    const void* norm_weight;        /* NULL or [k] */
+    float norm_eps;
+    int32_t epilogue;
+    const int64_t* positions;       /* ROPE_STORE only, below */
+    const float* cos_sin;
+    void* k_cache;
+    void* v_cache;
+    const int32_t* slot_mapping;
+    int32_t h, kvh, hd;
+} nvh_linear_desc;
+int nvh_linear_small_m_ex(const nvh_linear_desc* desc, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -274,9 +274,50 @@ int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias
     const int out_cols = silu_inter ? silu_inter : n;
     if (x_row_stride % 8 || x_row_stride < k || out_row_stride < out_cols) { set_error("linear_small_m: bad row strides"); return NVH_E_STRIDE; }
     if (!aligned16(x) || !aligned16(w)) { set_error("linear_small_m: x and w must be 16-byte aligned"); return NVH_E_ALIGN; }
+    nvh_linear_desc d = {};
+    d.out = out; d.x = x; d.w = w; d.bias = bias; d.m = m; d.n = n; d.k = k; d.silu_inter = silu_inter;
+    d.x_row_stride = x_row_stride; d.out_row_stride = out_row_stride;
+    d.epilogue = silu_inter ? NVH_EPI_SILU_MUL : NVH_EPI_NONE;
+    return nvh_linear_small_m_ex(&d, dtype, stream);
+}
+
+int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
+    if (!d) { set_error("linear_small_m_ex: null descriptor"); return NVH_E_NULL; }
+    if (d->m == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("linear_small_m_ex: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!d->out || !d->x || !d->w) { set_error("linear_small_m_ex: null pointer"); return NVH_E_NULL; }
+    if (d->m < 0 || d->m > 64 || d->n <= 0 || d->k <= 0 || d->k % 64 || d->n % 16) {
+        set_error("linear_small_m_ex: m=%d (<=64) n=%d (%%16) k=%d (%%64)", d->m, d->n, d->k);
+        return NVH_E_SHAPE;
+    }
+    int out_cols = d->n;
+    switch (d->epilogue) {
+        case NVH_EPI_NONE: break;
+        case NVH_EPI_SILU_MUL:
+            if (d->silu_inter * 2 != d->n || d->silu_inter % 16 || d->bias) { set_error("linear_small_m_ex: silu needs n == 2*inter, inter %% 16 == 0, no bias"); return NVH_E_SHAPE; }
+            out_cols = d->silu_inter;
+            break;
+        case NVH_EPI_RESIDUAL_ADD:
+            if (d->bias) { set_error("linear_small_m_ex: residual-add epilogue takes no bias"); return NVH_E_SHAPE; }
+            break;
+        case NVH_EPI_ROPE_STORE:
+            if ((d->hd != 64 && d->hd != 128) || d->h <= 0 || d->kvh <= 0 || (d->h + 2 * d->kvh) * d->hd != d->n) {
+                set_error("linear_small_m_ex: rope epilogue needs n == (h + 2*kvh) * hd, hd in {64,128}");
+                return NVH_E_SHAPE;
+            }
+            if (!d->positions || !d->cos_sin || !d->k_cache || !d->v_cache || !d->slot_mapping) { set_error("linear_small_m_ex: rope epilogue pointers"); return NVH_E_NULL; }
+            out_cols = d->h * d->hd;
+            break;
+        default: set_error("linear_small_m_ex: unknown epilogue %d", d->epilogue); return NVH_E_SHAPE;
+    }
+    if (d->x_row_stride % 8 || d->x_row_stride < d->k || d->out_row_stride < out_cols) { set_error("linear_small_m_ex: bad row strides"); return NVH_E_STRIDE; }
+    if (!aligned16(d->x) || !aligned16(d->w) || (d->norm_weight && !aligned16(d->norm_weight))) { set_error("linear_small_m_ex: x, w, norm_weight must be 16-byte aligned"); return NVH_E_ALIGN; }
     LinearArgs a;
-    a.out = out; a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.bias = (const uint16_t*)bias;
-    a.M = m; a.N = n; a.K = k; a.inter = silu_inter; a.x_stride = x_row_stride; a.out_stride = out_row_stride;
+    a.out = d->out; a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = (const uint16_t*)d->bias;
+    a.M = d->m; a.N = d->n; a.K = d->k; a.inter = d->silu_inter; a.x_stride = d->x_row_stride; a.out_stride = d->out_row_stride;
+    a.norm_w = (const uint16_t*)d->norm_weight; a.norm_eps = d->norm_eps; a.epi = d->epilogue;
+    a.positions = d->positions; a.cos_sin = d->cos_sin; a.k_cache = (uint16_t*)d->k_cache; a.v_cache = (uint16_t*)d->v_cache;
+    a.slots = d->slot_mapping; a.h = d->h; a.kvh = d->kvh; a.hd = d->hd;
     return launch_linear_small_m(a, (hipStream_t)stream);
 }
 

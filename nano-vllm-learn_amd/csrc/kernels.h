@@ -50,14 +50,25 @@ int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, 
 int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream);
 int max_rmsnorm_hidden(void);
 
+enum { EPI_NONE = 0, EPI_SILU = 1, EPI_RESADD = 2, EPI_ROPE = 3 };   // == NVH_EPI_* in nvh_attn.h
+
 struct LinearArgs {
-    void* out;                   // [M, N] bf16 (SILU mode: [M, inter])
+    void* out;                   // NONE: [M, N]; SILU: [M, inter]; RESADD: the residual stream [M, N], updated in place; ROPE: q [M, H*D]
     const uint16_t* x;           // [M, K] bf16, row stride x_stride
     const uint16_t* w;           // [N, K] bf16 contiguous (nn.Linear layout)
     const uint16_t* bias;        // [N] bf16 or null
     int M, N, K;
-    int inter;                   // > 0: SiLU(gate)*up epilogue, N == 2*inter, gate rows [0, inter), up rows [inter, 2*inter)
+    int inter;                   // SILU: N == 2*inter, gate rows [0, inter), up rows [inter, 2*inter)
     int64_t x_stride, out_stride;
+    const uint16_t* norm_w;      // non-null: RMSNorm prologue with this weight [K]
+    float norm_eps;
+    int epi;
+    const int64_t* positions;    // ROPE: [M]
+    const float* cos_sin;        // ROPE: [max_position, D]
+    uint16_t* k_cache;           // ROPE: paged caches and slots of this step's rows
+    uint16_t* v_cache;
+    const int32_t* slots;
+    int h, kvh, hd;              // ROPE: N == (h + 2*kvh) * hd
 };
 int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
 

@@ -14,6 +14,18 @@ LIB_PATH = os.path.join(_HERE, "lib", "libnvh_attn.so")
 NVH_BF16 = 0
 NVH_F32 = 1
 
+class LinearDesc(ctypes.Structure):
+    """nvh_linear_desc (include/nvh_attn.h)."""
+    _fields_ = [("out", ctypes.c_void_p), ("x", ctypes.c_void_p), ("w", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("m", ctypes.c_int32), ("n", ctypes.c_int32), ("k", ctypes.c_int32), ("silu_inter", ctypes.c_int32),
+                ("x_row_stride", ctypes.c_int64), ("out_row_stride", ctypes.c_int64),
+                ("norm_weight", ctypes.c_void_p), ("norm_eps", ctypes.c_float), ("epilogue", ctypes.c_int32),
+                ("positions", ctypes.c_void_p), ("cos_sin", ctypes.c_void_p), ("k_cache", ctypes.c_void_p), ("v_cache", ctypes.c_void_p),
+                ("slot_mapping", ctypes.c_void_p), ("h", ctypes.c_int32), ("kvh", ctypes.c_int32), ("hd", ctypes.c_int32)]
+
+
+EPI_NONE, EPI_SILU_MUL, EPI_RESIDUAL_ADD, EPI_ROPE_STORE = 0, 1, 2, 3
+
 _c_i32p = ctypes.c_void_p
 _SIGS = {
     "nvh_version": (ctypes.c_int, []),
@@ -35,6 +47,7 @@ _SIGS = {
                         [ctypes.c_int, ctypes.c_void_p]),
     "nvh_silu_mul": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "nvh_linear_small_m": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
+    "nvh_linear_small_m_ex": (ctypes.c_int, [ctypes.POINTER(LinearDesc), ctypes.c_int, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

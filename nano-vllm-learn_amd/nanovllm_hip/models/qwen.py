@@ -114,7 +114,7 @@ class RMSNorm(nn.Module):
 def linear(x, weight, bias=None):
     """F.linear; decode-sized batches on the GPU take the weight-streaming HIP kernel (ops.linear_small_m), anything
     else (prefill, CPU tests) goes to the vendor GEMM."""
-    if x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] <= 64 and x.shape[-1] % 32 == 0 and weight.shape[0] % 16 == 0:
+    if x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] <= 64 and x.shape[-1] % 64 == 0 and weight.shape[0] % 16 == 0:
         from .. import ops
         return ops.linear_small_m(x, weight, bias)
     return F.linear(x, weight, bias)
@@ -217,7 +217,7 @@ class QwenMLP(nn.Module):
 
     def forward(self, x):
         w = self.gate_up_proj.weight
-        if x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] <= 64 and x.shape[-1] % 32 == 0 and w.shape[0] % 32 == 0:
+        if x.is_cuda and x.dtype == torch.bfloat16 and x.numel() // x.shape[-1] <= 64 and x.shape[-1] % 64 == 0 and w.shape[0] % 32 == 0:
             from .. import ops
             act = ops.linear_small_m(x, w, silu_mul=True)         # gate_up projection + SiLU*mul in one launch
         else:
@@ -248,6 +248,14 @@ class QwenDecoderLayer(nn.Module):
         return self.mlp(hidden_states), residual
 
 
+def _fused_decode_ok(cfg, x):
+    """The 6-launch decoder layer (nvh_linear_small_m_ex) applies to single-GPU decode batches of at most 64 rows."""
+    from ..utils.context import get_context
+    ctx = get_context()
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[0] <= 64 and not ctx.is_prefill and ctx.context_lens is not None
+            and ctx.slot_mapping is not None and not cfg.qk_norm and _tp()[1] == 1 and cfg.attn_backend == "hip")
+
+
 class QwenForCausalLM(nn.Module):
     def __init__(self, cfg: ModelConfig):
         super().__init__()
@@ -260,13 +268,42 @@ class QwenForCausalLM(nn.Module):
 
     def forward(self, input_ids, positions):
         h, residual = self.embed_tokens(input_ids), None
+        if _fused_decode_ok(self.cfg, h):
+            return self._forward_decode_fused(h, positions)
         for layer in self.layers:
             h, residual = layer(positions, h, residual)
         h, _ = self.norm(h, residual)
         return h
 
+    def _forward_decode_fused(self, residual, positions):
+        """Decode step with 6 launches per layer: norms ride in the GEMM prologues, residual adds / SiLU*mul / RoPE+store in
+        the epilogues.  `residual` is the running residual stream (the embedding output, updated in place); the final norm is
+        applied by compute_logits' prologue, so this returns the un-normalised stream tagged for that."""
+        from .. import ops
+        from ..utils.context import get_context
+        ctx = get_context()
+        for layer in self.layers:
+            a, mlp = layer.self_attn, layer.mlp
+            q = ops.fused_linear(residual, a.qkv_proj.weight, bias=a.qkv_proj.bias, norm_weight=layer.input_layernorm.weight,
+                                 norm_eps=layer.input_layernorm.eps, epilogue="rope_store",
+                                 rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
+                                           v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
+                                           num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
+            o = a.attn.decode_attend(q)
+            ops.fused_linear(o, a.o_proj.weight, epilogue="residual_add", out=residual)
+            # wide projections pre-normalise once (the prologue would be recomputed by every one of their N/16 workgroups)
+            y = ops.add_rmsnorm(residual, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
+            act = ops.fused_linear(y, mlp.gate_up_proj.weight, epilogue="silu_mul")
+            ops.fused_linear(act, mlp.down_proj.weight, epilogue="residual_add", out=residual)
+        self._pending_final_norm = True
+        return residual
+
     def compute_logits(self, hidden_states):
         w = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight
+        if getattr(self, "_pending_final_norm", False):              # fused decode path: final RMSNorm in the LM-head prologue
+            self._pending_final_norm = False
+            from .. import ops
+            return ops.fused_linear(ops.add_rmsnorm(hidden_states, self.norm.weight, self.norm.eps), w)
         return linear(hidden_states, w)
 
     @torch.no_grad()

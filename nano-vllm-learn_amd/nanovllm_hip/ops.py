@@ -9,6 +9,8 @@ a GPU and the HIP library must load.
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
@@ -271,3 +273,44 @@ def linear_small_m(x, weight, bias=None, silu_mul=False):
                                         x2.shape[0], n, k, inter, x2.stride(0), out.stride(0), NVH_BF16, _stream())
     _lib.check(rc, "nvh_linear_small_m")
     return out.view(*x.shape[:-1], out.shape[1])
+
+
+def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, epilogue="none", out=None, rope=None):
+    """nvh_linear_small_m_ex: x [M<=64, K] . weight[N, K]^T with an optional RMSNorm prologue and one of the epilogues
+    "none" (+bias) | "silu_mul" | "residual_add" (out = the residual stream, updated in place) | "rope_store"
+    (rope = dict(positions, cos_sin, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads, head_dim); returns q [M, H*D])."""
+    _require_gpu_bf16(x=x, weight=weight)
+    m, k = x.shape
+    n = weight.shape[0]
+    assert x.stride(1) == 1 and weight.is_contiguous() and weight.shape[1] == k and m <= LINEAR_SMALL_M_MAX
+    d = _lib.LinearDesc()
+    d.x, d.w, d.m, d.n, d.k, d.x_row_stride = x.data_ptr(), weight.data_ptr(), m, n, k, x.stride(0)
+    d.bias = bias.data_ptr() if bias is not None else None
+    if norm_weight is not None:
+        _require_gpu_bf16(norm_weight=norm_weight)
+        assert norm_weight.numel() == k
+        d.norm_weight, d.norm_eps = norm_weight.data_ptr(), float(norm_eps)
+    if epilogue == "none":
+        d.epilogue, cols = _lib.EPI_NONE, n
+    elif epilogue == "silu_mul":
+        d.epilogue, d.silu_inter, cols = _lib.EPI_SILU_MUL, n // 2, n // 2
+    elif epilogue == "residual_add":
+        assert out is not None and out.shape == (m, n) and out.dtype == torch.bfloat16 and out.stride(1) == 1
+        d.epilogue, cols = _lib.EPI_RESIDUAL_ADD, n
+    elif epilogue == "rope_store":
+        h, kvh, hd = rope["num_heads"], rope["num_kv_heads"], rope["head_dim"]
+        _require_i32(slot_mapping=rope["slot_mapping"])
+        assert rope["positions"].dtype == torch.int64 and rope["cos_sin"].dtype == torch.float32 and rope["cos_sin"].is_contiguous()
+        assert rope["k_cache"].is_contiguous() and rope["v_cache"].is_contiguous()
+        d.epilogue, cols = _lib.EPI_ROPE_STORE, h * hd
+        d.positions, d.cos_sin = rope["positions"].data_ptr(), rope["cos_sin"].data_ptr()
+        d.k_cache, d.v_cache, d.slot_mapping = rope["k_cache"].data_ptr(), rope["v_cache"].data_ptr(), rope["slot_mapping"].data_ptr()
+        d.h, d.kvh, d.hd = h, kvh, hd
+    else:
+        raise ValueError(epilogue)
+    if out is None:
+        out = torch.empty((m, cols), dtype=torch.bfloat16, device=x.device)
+    d.out, d.out_row_stride = out.data_ptr(), out.stride(0)
+    rc = _lib.load().nvh_linear_small_m_ex(ctypes.byref(d), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_linear_small_m_ex")
+    return out

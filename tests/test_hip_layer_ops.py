@@ -99,3 +99,118 @@ def test_linear_small_m_silu(m, inter, k):
     # the fused kernel rounds the same fp32 sums to bf16; summation order can flip a rounding of gate or up (<= 1 ulp each)
     assert (err <= 2.0 ** -6 * ref.float().abs() + 2e-3).all(), err.max()
     assert (err > 2.0 ** -8 * ref.float().abs() + 1e-4).float().mean() < 0.05
+
+
+def _ref_rms(x, w, eps):
+    x32 = x.float()
+    return (x32 * torch.rsqrt(x32.pow(2).mean(dim=-1, keepdim=True) + eps)).to(x.dtype) * w
+
+
+def _close(a, b, rel=2.0 ** -6, abs_=3e-3, frac=0.05):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    assert (err <= rel * b.abs() + abs_).all(), err.max()
+    assert (err > 2.0 ** -8 * b.abs() + abs_ / 10).float().mean() < frac
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 896, 896), (32, 151936, 896), (7, 576, 3584)])
+def test_fused_linear_norm_prologue(m, n, k):
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(m + n)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().cuda()
+    gw = (1 + 0.2 * torch.randn(k, generator=g)).bfloat16().cuda()
+    ref = torch.nn.functional.linear(_ref_rms(x, gw, 1e-6).float(), w.float())
+    out = ops.fused_linear(x, w, norm_weight=gw, norm_eps=1e-6)
+    torch.cuda.synchronize()
+    _close(out, ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 896, 896), (32, 896, 4864), (3, 3584, 18944)])
+def test_fused_linear_residual_add(m, n, k):
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.02).bfloat16().cuda()
+    res = torch.randn(m, n, generator=g).bfloat16().cuda()
+    ref = torch.nn.functional.linear(x.float(), w.float()) + res.float()
+    ops.fused_linear(x, w, epilogue="residual_add", out=res)
+    torch.cuda.synchronize()
+    _close(res, ref)
+
+
+def test_fused_linear_silu_with_norm():
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(5)
+    m, k, inter = 32, 896, 4864
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(2 * inter, k, generator=g) * 0.05).bfloat16().cuda()
+    gw = (1 + 0.2 * torch.randn(k, generator=g)).bfloat16().cuda()
+    gu = torch.nn.functional.linear(_ref_rms(x, gw, 1e-6).float(), w.float()).bfloat16()
+    ref = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+    out = ops.fused_linear(x, w, norm_weight=gw, norm_eps=1e-6, epilogue="silu_mul")
+    torch.cuda.synchronize()
+    _close(out, ref, rel=2.0 ** -5)
+
+
+@pytest.mark.parametrize("H,KVH,D", [(14, 2, 64), (7, 1, 128)])
+def test_fused_linear_rope_store_equals_linear_then_rope_store(H, KVH, D):
+    """qkv projection with the RoPE+store epilogue == skinny GEMM followed by nvh_rope_store (itself bit-exact against the
+    reference's RoPE): q identical, cache rows identical, -1 slots skipped."""
+    from nanovllm_hip import ops
+    from nanovllm_hip.models.qwen import cos_sin_table
+    g = torch.Generator().manual_seed(H)
+    m, k, bs, nb = 32, 896, 256, 3
+    n = (H + 2 * KVH) * D
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(n, generator=g).bfloat16().cuda()
+    pos = torch.randint(0, 4096, (m,), generator=g).cuda()
+    slots = torch.randperm(nb * bs, generator=g)[:m].int()
+    slots[2::9] = -1
+    slots = slots.cuda()
+    table = cos_sin_table(D, 4096, 1e6, "cuda")
+    kc1 = torch.randn(nb, bs, KVH, D, generator=g).bfloat16().cuda()
+    vc1 = torch.randn(nb, bs, KVH, D, generator=g).bfloat16().cuda()
+    kc2, vc2 = kc1.clone(), vc1.clone()
+    qkv = ops.linear_small_m(x, w, b)
+    ops.rope_store(qkv, pos, table, H, KVH, D, kc1, vc1, slots)
+    q = ops.fused_linear(x, w, bias=b, epilogue="rope_store",
+                         rope=dict(positions=pos, cos_sin=table, k_cache=kc2, v_cache=vc2, slot_mapping=slots, num_heads=H, num_kv_heads=KVH, head_dim=D))
+    torch.cuda.synchronize()
+    assert torch.equal(q, qkv[:, :H * D])
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+
+
+def test_fused_decode_layer_path_close_to_unfused():
+    """The 6-launch decode path (norm prologues, residual/SiLU/RoPE epilogues) against the 10-launch path on the same
+    weights and cache state: logits agree to bf16 accumulation noise."""
+    from nanovllm_hip.engine.llm_engine import LLMEngine
+    from nanovllm_hip.engine.model_runner import build_decode_meta
+    from nanovllm_hip.engine.sequence import Sequence
+    from nanovllm_hip.models import qwen
+    from nanovllm_hip import reset_context, set_context
+    cfg = qwen.model_config("Qwen2-0.5B", num_hidden_layers=3, vocab_size=4096)
+    g = torch.Generator().manual_seed(0)
+    prompts = [torch.randint(0, 4096, (n,), generator=g).tolist() for n in (300, 40, 257)]
+    logits = []
+    for fused in (True, False):
+        eng = LLMEngine(cfg, num_kvcache_blocks=12, seed=2)
+        seqs = [Sequence(p, max_tokens=4) for p in prompts]
+        eng.prefill(seqs, reserve_tokens=4)
+        m = build_decode_meta(seqs)
+        dev = lambda t: t.cuda()
+        orig = qwen._fused_decode_ok
+        if not fused:
+            qwen._fused_decode_ok = lambda cfg_, x: False
+        try:
+            with torch.inference_mode():
+                set_context(False, slot_mapping=dev(m["slot_mapping"]), context_lens=dev(m["context_lens"]), block_tables=dev(m["block_tables"]))
+                h = eng.runner.model(dev(m["input_ids"]), dev(m["positions"]))
+                logits.append(eng.runner.model.compute_logits(h).float().cpu())
+                reset_context()
+        finally:
+            qwen._fused_decode_ok = orig
+    scale = logits[1].abs().max()
+    assert (logits[0] - logits[1]).abs().max() <= 3e-2 * scale
+    assert (logits[0].argmax(-1) == logits[1].argmax(-1)).all()
