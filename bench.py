@@ -14,9 +14,9 @@ region (it is reported separately, and the bench_my-style figure that includes i
 The K timed steps start at context 1025 as bench_my's decode phase does (K = 1024 covers 1025 -> 2048).
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the decode attention op (nvh_decode_step: store + split-KV attention + combine) at the mean
-                context of the timed window, timed live with HIP events on the launching stream over a graph
-                of per-layer calls on distinct caches; achieved = algorithmic bytes / average time per call.
+  roofline      the decode attention op (nvh_paged_decode: split-KV attention + combine) at the mean context of the
+                timed window, timed live with HIP events on the launching stream over a graph of per-layer calls
+                on distinct caches; achieved = algorithmic bytes / average time per call.
   cpu_baseline  the CPU port of the reference's sdpa.math decode (oracle/sdpa_math_cpu.py, "port"), timed on
                 this host on a bounded sample of the same attention call; rank 0, N = 1 only.
 """
@@ -69,9 +69,9 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     out = torch.empty(batch, h, d, device=dev, dtype=torch.bfloat16)
     ops.reserve_workspace(dev, ops.decode_workspace_bytes(batch, h, d, nblk, bs))
 
-    def calls():
-        for c in caches:
-            ops.decode_step(q, k, v, c[0], c[1], slots, cl, bt, out=out)
+    def calls():                                   # exactly what a decoder layer launches for attention at decode: split + combine
+        for c in caches:                           # (the K/V store rides in the qkv projection's epilogue, nvh_linear_small_m_ex)
+            ops.flash_attn_with_kvcache(q, c[0], c[1], cl, bt, out=out)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -92,7 +92,7 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     end.record()
     torch.cuda.synchronize()
     us = start.elapsed_time(end) * 1e3 / (iters * layers)
-    nbytes = decode_attn_bytes([ctx] * batch, h, kvh, d, bs)
+    nbytes = decode_attn_bytes([ctx] * batch, h, kvh, d, bs, with_store=False)
     return us, nbytes, (h, kvh, d)
 
 
@@ -232,7 +232,7 @@ def main():
                        "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(cfg, tp, args.batch, mean_ctx),
-                         "kernel": "one decode attention call = paged_decode_split_mfma (dominant) + paged_decode_combine (+ store_kvcache in this leg)",
+                         "kernel": "one decode attention call (nvh_paged_decode) = paged_decode_split_mfma (dominant) + paged_decode_combine",
                          "bytes_per_launch": attn_bytes, "us_per_launch": round(attn_us, 2), "context": mean_ctx,
                          "shape_per_rank": list(shape_rank)},
             "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),
