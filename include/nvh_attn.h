@@ -155,6 +155,9 @@ int nvh_add_rmsnorm(void* out, const void* x, void* residual, const void* weight
                     int64_t x_row_stride, int64_t out_row_stride, int64_t residual_row_stride, int dtype, void* stream);
 int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gate_up_row_stride, int64_t out_row_stride,
                  int dtype, void* stream);
+/*   nvh_argmax_rows  greedy sampling (temperature 0; nanovllm/layers/sampler.py, bench_my.py:31): out[i] = argmax_j x[i, j],
+ *                    int64, ties -> lowest index; x [n_rows, n] bf16, 16-byte aligned rows (row stride % 8 == 0). */
+int nvh_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t x_row_stride, int dtype, void* stream);
 
 /*
  * Engine widening: weight-streaming linear layer for decode-sized batches, out = x . W^T (+ bias), m <= 64 rows.

@@ -264,6 +264,16 @@ int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t 
     return launch_silu_mul(out, gate_up, n_rows, inter, gate_up_row_stride, out_row_stride, (hipStream_t)stream);
 }
 
+int nvh_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t x_row_stride, int dtype, void* stream) {
+    if (n_rows == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("argmax_rows: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!out || !x) { set_error("argmax_rows: null pointer"); return NVH_E_NULL; }
+    if (n_rows < 0 || n <= 0) { set_error("argmax_rows: bad shape"); return NVH_E_SHAPE; }
+    if (x_row_stride % 8 || x_row_stride < n) { set_error("argmax_rows: row stride must be a multiple of 8 and >= n"); return NVH_E_STRIDE; }
+    if (!aligned16(x)) { set_error("argmax_rows: x must be 16-byte aligned"); return NVH_E_ALIGN; }
+    return launch_argmax_rows(out, x, n_rows, n, x_row_stride, (hipStream_t)stream);
+}
+
 int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias, int m, int n, int k, int silu_inter,
                        int64_t x_row_stride, int64_t out_row_stride, int dtype, void* stream) {
     if (m == 0) return 0;

@@ -49,6 +49,7 @@ int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, 
                        int64_t x_stride, int64_t out_stride, int64_t res_stride, hipStream_t stream);
 int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream);
 int max_rmsnorm_hidden(void);
+int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, hipStream_t stream);
 
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_RESADD = 2, EPI_ROPE = 3 };   // == NVH_EPI_* in nvh_attn.h
 

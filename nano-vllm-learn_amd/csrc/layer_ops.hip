@@ -102,7 +102,52 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
     }
 }
 
+// Greedy sampling: argmax over each row of bf16 logits (nanovllm/layers/sampler.py at temperature 0 reduces to this).
+// One 1024-thread workgroup per row streams the row with 16-byte loads; ties resolve to the lowest index.
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__ out, const uint16_t* __restrict__ x, int n, int64_t stride) {
+    __shared__ float lds_v[16];
+    __shared__ int lds_i[16];
+    const uint16_t* row = x + blockIdx.x * stride;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    const int chunks = n / 8;
+    for (int c = threadIdx.x; c < chunks; c += 1024) {
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(row + c * 8));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float lo = bf16_lo(v[k]), hi = bf16_hi(v[k]);
+            if (lo > best) { best = lo; bidx = c * 8 + 2 * k; }            // ascending index order inside a thread: first max wins
+            if (hi > best) { best = hi; bidx = c * 8 + 2 * k + 1; }
+        }
+    }
+    for (int i = chunks * 8 + threadIdx.x; i < n; i += 1024) {              // tail when n % 8 != 0
+        const float f = bf16_lo((uint32_t)row[i]);
+        if (f > best) { best = f; bidx = i; }
+    }
+    // wave reduce (value desc, index asc), then across the 16 waves
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { lds_v[wave] = best; lds_i[wave] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w)
+            if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+        out[blockIdx.x] = bidx;
+    }
+}
+
 }  // namespace
+
+int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, hipStream_t stream) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_rows), dim3(1024), 0, stream, out, (const uint16_t*)x, n, stride);
+    return check_launch("argmax_rows");
+}
 
 int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, float eps, int n_rows, int hidden,
                        int64_t x_stride, int64_t out_stride, int64_t res_stride, hipStream_t stream) {

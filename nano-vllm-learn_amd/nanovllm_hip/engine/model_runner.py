@@ -26,6 +26,13 @@ from .sequence import Sequence
 
 
 # ----------------------------------------------------------------------------- metadata producers (host, CPU tensors)
+def greedy_tokens(logits):
+    """Temperature-0 sampling (sampler.py with bench_my's settings): one HIP launch on the GPU."""
+    if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.stride(-1) == 1 and logits.stride(0) % 8 == 0:
+        return ops.argmax_rows(logits)
+    return logits.argmax(dim=-1)
+
+
 def build_block_tables(seqs, width=None, pad=-1):
     width = width or max(len(s.block_table) for s in seqs)
     rows = [s.block_table + [pad] * (width - len(s.block_table)) for s in seqs]
@@ -111,7 +118,7 @@ class ModelRunner:
         if is_prefill:
             last = self._dev(m["cu_seqlens_q"])[1:].long() - 1                     # last token of every sequence (embed_head.py:62-65)
             hidden = hidden[last]
-        tokens = self.model.compute_logits(hidden).argmax(dim=-1)
+        tokens = greedy_tokens(self.model.compute_logits(hidden))
         reset_context()
         return tokens.tolist()
 
@@ -173,7 +180,7 @@ class DecodeSession:
     def _step(self):
         set_context(False, slot_mapping=self.slot_mapping, context_lens=self.context_lens, block_tables=self.block_tables)
         hidden = self.runner.model(self.input_ids, self.positions)
-        self._advance(self.runner.model.compute_logits(hidden).argmax(dim=-1))
+        self._advance(greedy_tokens(self.runner.model.compute_logits(hidden)))
         reset_context()
 
     @torch.inference_mode()

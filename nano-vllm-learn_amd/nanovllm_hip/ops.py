@@ -314,3 +314,13 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, epilo
     rc = _lib.load().nvh_linear_small_m_ex(ctypes.byref(d), NVH_BF16, _stream())
     _lib.check(rc, "nvh_linear_small_m_ex")
     return out
+
+
+def argmax_rows(logits):
+    """Greedy token per row: argmax over the last dim of bf16 logits [M, N] (ties -> lowest index), int64."""
+    _require_gpu_bf16(logits=logits)
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    out = torch.empty(logits.shape[0], dtype=torch.int64, device=logits.device)
+    rc = _lib.load().nvh_argmax_rows(out.data_ptr(), logits.data_ptr(), logits.shape[0], logits.shape[1], logits.stride(0), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_argmax_rows")
+    return out

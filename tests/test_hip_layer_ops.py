@@ -214,3 +214,20 @@ def test_fused_decode_layer_path_close_to_unfused():
     scale = logits[1].abs().max()
     assert (logits[0] - logits[1]).abs().max() <= 3e-2 * scale
     assert (logits[0].argmax(-1) == logits[1].argmax(-1)).all()
+
+
+@pytest.mark.parametrize("m,n", [(32, 151936), (1, 1000), (5, 152064), (3, 17)])
+def test_argmax_rows(m, n):
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(m, n, generator=g).bfloat16()
+    x[0, min(7, n - 1)] = 9.0
+    x[0, min(11, n - 1)] = 9.0                                # a tie: the lowest index must win
+    stride = (n + 7) // 8 * 8
+    buf = torch.zeros(m, stride, dtype=torch.bfloat16)
+    buf[:, :n] = x
+    xd = buf.cuda()[:, :n]
+    got = ops.argmax_rows(xd).cpu()
+    vals = x.float()
+    exp = torch.tensor([int((vals[i] == vals[i].max()).nonzero()[0]) for i in range(m)])
+    assert torch.equal(got, exp)
