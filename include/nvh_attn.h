@@ -176,6 +176,9 @@ int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias
  * The same weight-streaming product with the neighbouring row-wise ops of a decoder layer fused in, so that a decode
  * layer is 6 launches (qkv, attention split, attention combine, o_proj, gate_up, down) instead of 10:
  *   norm_weight != NULL : prologue x := RMSNorm(x) * norm_weight   (RMSNorm.rms_forward, nanovllm/layers/layernorm.py:17-27)
+ *   norm_folded != 0    : the same norm with its weight already multiplied into w by the caller (w := w * diag(norm_weight));
+ *                         sum(x^2) is taken inside the K loop and rows are scaled by rsqrt(mean(x^2) + norm_eps) in the epilogue
+ *                         (same algebra, without re-rounding the normalised activations to bf16); norm_weight must be NULL
  *   epilogue NVH_EPI_NONE          out [m, n] = product + bias
  *            NVH_EPI_SILU_MUL      as nvh_linear_small_m with silu_inter
  *            NVH_EPI_RESIDUAL_ADD  out is the residual stream [m, n]: out += product, in place (the add of
@@ -204,6 +207,7 @@ typedef struct nvh_linear_desc {
     void* v_cache;
     const int32_t* slot_mapping;
     int32_t h, kvh, hd;
+    int32_t norm_folded;
 } nvh_linear_desc;
 int nvh_linear_small_m_ex(const nvh_linear_desc* desc, int dtype, void* stream);
 

@@ -325,7 +325,9 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     LinearArgs a;
     a.out = d->out; a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = (const uint16_t*)d->bias;
     a.M = d->m; a.N = d->n; a.K = d->k; a.inter = d->silu_inter; a.x_stride = d->x_row_stride; a.out_stride = d->out_row_stride;
+    if (d->norm_folded && d->norm_weight) { set_error("linear_small_m_ex: norm_folded excludes norm_weight"); return NVH_E_NULL; }
     a.norm_w = (const uint16_t*)d->norm_weight; a.norm_eps = d->norm_eps; a.epi = d->epilogue;
+    a.norm_mode = d->norm_folded ? 2 : (d->norm_weight ? 1 : 0);
     a.positions = d->positions; a.cos_sin = d->cos_sin; a.k_cache = (uint16_t*)d->k_cache; a.v_cache = (uint16_t*)d->v_cache;
     a.slots = d->slot_mapping; a.h = d->h; a.kvh = d->kvh; a.hd = d->hd;
     return launch_linear_small_m(a, (hipStream_t)stream);

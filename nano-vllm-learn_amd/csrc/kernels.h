@@ -61,8 +61,9 @@ struct LinearArgs {
     int M, N, K;
     int inter;                   // SILU: N == 2*inter, gate rows [0, inter), up rows [inter, 2*inter)
     int64_t x_stride, out_stride;
-    const uint16_t* norm_w;      // non-null: RMSNorm prologue with this weight [K]
+    const uint16_t* norm_w;      // norm_mode 1: RMSNorm weight [K]
     float norm_eps;
+    int norm_mode;               // 0 none; 1 exact RMSNorm prologue; 2 folded RMSNorm (w already multiplied by the norm weight)
     int epi;
     const int64_t* positions;    // ROPE: [M]
     const float* cos_sin;        // ROPE: [max_position, D]

@@ -5,7 +5,9 @@
 // add_rmsnorm, rope_store and the attention combine all sit at 4.8-5.0 us), and hipBLASLt needs 10-13 us for these 2-17 MB
 // weight streams.  Folding the norms and the elementwise tails into the GEMMs takes a decoder layer from 10 launches to 6.
 //
-//   prologue  NORM      x := bf16(bf16(x * rsqrt(mean(x^2) + eps)) * g)      RMSNorm.rms_forward, layers/layernorm.py:17-27
+//   prologue  NORM 1    x := bf16(bf16(x * rsqrt(mean(x^2) + eps)) * g)      RMSNorm.rms_forward, layers/layernorm.py:17-27
+//             NORM 2    the same norm folded: W already holds g*W (caller), sum(x^2) is accumulated from the x fragments
+//                       in the K loop and the row scale is applied in the epilogue (no extra pass, no bf16 re-rounding of x)
 //   epilogue  NONE      + bias                                                 F.linear (layers/linear.py)
 //             SILU      SiLU(x gate^T) * (x up^T), gate rows [0,inter), up rows [inter,2 inter)   layers/activation.py:11-14
 //             RESADD    out (the residual stream, in place) += product         the add of add_rms_forward, layernorm.py:35-36
@@ -29,7 +31,7 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MT, int WAVES, int EPI, bool NORM>
+template <int MT, int WAVES, int EPI, int NORM>
 __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const LinearArgs a) {
     constexpr int NB = (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;           // weight row blocks per workgroup
     constexpr int GS = WAVES == 8 ? 4 : 8;                                     // k-steps staged per group (per wave)
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
 
     // ---- prologue: RMSNorm scale of every row this lane feeds into the MFMA (row 16m + lq)
     float inv[MT];
-    if constexpr (NORM) {
+    if constexpr (NORM == 1) {
         float ss[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) ss[m] = 0.f;
@@ -112,6 +114,9 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
     }
 
     f32x4 acc[NB][MT];
+    float ss2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ss2[m] = 0.f;
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
             const int ks = g0 + i < ks1 ? g0 + i : ks1 - 1;
 #pragma unroll
             for (int m = 0; m < MT; ++m) araw[i][m] = *reinterpret_cast<const u32x4*>(xrow[m] + ks * 32);
-            if constexpr (NORM) graw[i] = *reinterpret_cast<const u32x4*>(a.norm_w + ks * 32 + lg * 8);
+            if constexpr (NORM == 1) graw[i] = *reinterpret_cast<const u32x4*>(a.norm_w + ks * 32 + lg * 8);
         }
 #pragma unroll
         for (int pi = 0; pi < GS / 2; ++pi) {                                  // piece pi of the group = k-steps g0+2pi, g0+2pi+1
@@ -168,7 +173,16 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 u32x4 av = araw[i][m];
-                if constexpr (NORM) {
+                if constexpr (NORM == 2) {                         // folded norm: only sum(x^2) is needed; the scale is applied in the epilogue
+                    float q = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float lo = bf16_lo(av[w]), hi = bf16_hi(av[w]);
+                        q += lo * lo + hi * hi;
+                    }
+                    ss2[m] += live ? q : 0.f;
+                }
+                if constexpr (NORM == 1) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const float lo = (float)(__bf16)(bf16_lo(av[w]) * inv[m]) * bf16_lo(graw[i][w]);
@@ -185,6 +199,14 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // LDS reads done before the next group's DMA overwrites
     }
     // ---- reduce the K chunks of the waves
+    if constexpr (NORM == 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ss2[m] = sum_xor16(ss2[m]);
+            ss2[m] = sum_xor32(ss2[m]);
+            if (lg == 0) lds_ss[wave][m][lq] = ss2[m];
+        }
+    }
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
@@ -202,6 +224,14 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
             s[nb] = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) s[nb] += (*reinterpret_cast<const red_t*>(lds_raw + w * WAVE_STAGE))[nb][mt][l][r];
+        }
+        if constexpr (NORM == 2) {                                 // x.(g*W)^T * rsqrt(mean(x^2)+eps) == RMSNorm(x).W^T without the two bf16 roundings
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) t += lds_ss[w][mt][row & 15];
+            const float inv_row = rsqrtf(t / a.K + a.norm_eps);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) s[nb] *= inv_row;
         }
         __bf16* const out = reinterpret_cast<__bf16*>(a.out);
         if constexpr (EPI == EPI_SILU) {
@@ -248,7 +278,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
     }
 }
 
-template <int MT, int EPI, bool NORM>
+template <int MT, int EPI, int NORM>
 int launch_w(const LinearArgs& a, hipStream_t stream) {
     int wgs;
     if (EPI == EPI_ROPE) wgs = (a.h + 2 * a.kvh) * (a.hd / 32);
@@ -261,13 +291,17 @@ int launch_w(const LinearArgs& a, hipStream_t stream) {
 
 template <int MT>
 int launch_mt(const LinearArgs& a, hipStream_t stream) {
-    const bool norm = a.norm_w != nullptr;
+    const int norm = a.norm_mode;                                  // 0 none, 1 exact prologue, 2 folded (scale in the epilogue)
+#define NVH_EPI_CASE(E)                                                            \
+    case E:                                                                        \
+        return norm == 2 ? launch_w<MT, E, 2>(a, stream) : norm == 1 ? launch_w<MT, E, 1>(a, stream) : launch_w<MT, E, 0>(a, stream);
     switch (a.epi) {
-        case EPI_NONE: return norm ? launch_w<MT, EPI_NONE, true>(a, stream) : launch_w<MT, EPI_NONE, false>(a, stream);
-        case EPI_SILU: return norm ? launch_w<MT, EPI_SILU, true>(a, stream) : launch_w<MT, EPI_SILU, false>(a, stream);
-        case EPI_RESADD: return norm ? launch_w<MT, EPI_RESADD, true>(a, stream) : launch_w<MT, EPI_RESADD, false>(a, stream);
-        case EPI_ROPE: return norm ? launch_w<MT, EPI_ROPE, true>(a, stream) : launch_w<MT, EPI_ROPE, false>(a, stream);
+        NVH_EPI_CASE(EPI_NONE)
+        NVH_EPI_CASE(EPI_SILU)
+        NVH_EPI_CASE(EPI_RESADD)
+        NVH_EPI_CASE(EPI_ROPE)
     }
+#undef NVH_EPI_CASE
     set_error("linear_small_m: unknown epilogue %d", a.epi);
     return -2;
 }

@@ -21,7 +21,8 @@ class LinearDesc(ctypes.Structure):
                 ("x_row_stride", ctypes.c_int64), ("out_row_stride", ctypes.c_int64),
                 ("norm_weight", ctypes.c_void_p), ("norm_eps", ctypes.c_float), ("epilogue", ctypes.c_int32),
                 ("positions", ctypes.c_void_p), ("cos_sin", ctypes.c_void_p), ("k_cache", ctypes.c_void_p), ("v_cache", ctypes.c_void_p),
-                ("slot_mapping", ctypes.c_void_p), ("h", ctypes.c_int32), ("kvh", ctypes.c_int32), ("hd", ctypes.c_int32)]
+                ("slot_mapping", ctypes.c_void_p), ("h", ctypes.c_int32), ("kvh", ctypes.c_int32), ("hd", ctypes.c_int32),
+                ("norm_folded", ctypes.c_int32)]
 
 
 EPI_NONE, EPI_SILU_MUL, EPI_RESIDUAL_ADD, EPI_ROPE_STORE = 0, 1, 2, 3

@@ -275,25 +275,41 @@ class QwenForCausalLM(nn.Module):
         h, _ = self.norm(h, residual)
         return h
 
+    def _folded_weights(self):
+        """RMSNorm weights multiplied into the projections that consume the normalised activations (w := w * diag(g)),
+        built once: RMSNorm(x) @ W^T == (x @ (g*W)^T) * rsqrt(mean(x^2) + eps), which nvh_linear_small_m_ex evaluates with the
+        row scale in its epilogue — no separate norm launch and no second pass over x."""
+        if getattr(self, "_folded", None) is None:
+            with torch.no_grad():
+                def fold(w, g):
+                    return (w.float() * g.float().unsqueeze(0)).to(torch.bfloat16).contiguous()
+                head = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight
+                self._folded = dict(
+                    qkv=[fold(l.self_attn.qkv_proj.weight, l.input_layernorm.weight) for l in self.layers],
+                    gate_up=[fold(l.mlp.gate_up_proj.weight, l.post_attention_layernorm.weight) for l in self.layers],
+                    head=fold(head, self.norm.weight))
+        return self._folded
+
     def _forward_decode_fused(self, residual, positions):
-        """Decode step with 6 launches per layer: norms ride in the GEMM prologues, residual adds / SiLU*mul / RoPE+store in
-        the epilogues.  `residual` is the running residual stream (the embedding output, updated in place); the final norm is
-        applied by compute_logits' prologue, so this returns the un-normalised stream tagged for that."""
+        """Decode step with 6 launches per layer (qkv, attention split + combine, o_proj, gate_up, down): the norms ride in the
+        projections (folded weights + epilogue row scale), residual adds / SiLU*mul / RoPE+store are GEMM epilogues.
+        `residual` is the running residual stream (the embedding output, updated in place); the final norm belongs to the LM
+        head's launch, so this returns the un-normalised stream and flags compute_logits."""
         from .. import ops
         from ..utils.context import get_context
         ctx = get_context()
-        for layer in self.layers:
+        fw = self._folded_weights()
+        for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
-            q = ops.fused_linear(residual, a.qkv_proj.weight, bias=a.qkv_proj.bias, norm_weight=layer.input_layernorm.weight,
-                                 norm_eps=layer.input_layernorm.eps, epilogue="rope_store",
+            q = ops.fused_linear(residual, fw["qkv"][i], bias=a.qkv_proj.bias, norm_folded=True, norm_eps=layer.input_layernorm.eps,
+                                 epilogue="rope_store",
                                  rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
                                            v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
                                            num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
             o = a.attn.decode_attend(q)
             ops.fused_linear(o, a.o_proj.weight, epilogue="residual_add", out=residual)
-            # wide projections pre-normalise once (the prologue would be recomputed by every one of their N/16 workgroups)
-            y = ops.add_rmsnorm(residual, layer.post_attention_layernorm.weight, layer.post_attention_layernorm.eps)
-            act = ops.fused_linear(y, mlp.gate_up_proj.weight, epilogue="silu_mul")
+            act = ops.fused_linear(residual, fw["gate_up"][i], norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
+                                   epilogue="silu_mul")
             ops.fused_linear(act, mlp.down_proj.weight, epilogue="residual_add", out=residual)
         self._pending_final_norm = True
         return residual
@@ -303,7 +319,7 @@ class QwenForCausalLM(nn.Module):
         if getattr(self, "_pending_final_norm", False):              # fused decode path: final RMSNorm in the LM-head prologue
             self._pending_final_norm = False
             from .. import ops
-            return ops.fused_linear(ops.add_rmsnorm(hidden_states, self.norm.weight, self.norm.eps), w)
+            return ops.fused_linear(hidden_states, self._folded_weights()["head"], norm_folded=True, norm_eps=self.norm.eps)
         return linear(hidden_states, w)
 
     @torch.no_grad()

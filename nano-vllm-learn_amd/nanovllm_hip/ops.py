@@ -275,7 +275,7 @@ def linear_small_m(x, weight, bias=None, silu_mul=False):
     return out.view(*x.shape[:-1], out.shape[1])
 
 
-def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, epilogue="none", out=None, rope=None):
+def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_folded=False, epilogue="none", out=None, rope=None):
     """nvh_linear_small_m_ex: x [M<=64, K] . weight[N, K]^T with an optional RMSNorm prologue and one of the epilogues
     "none" (+bias) | "silu_mul" | "residual_add" (out = the residual stream, updated in place) | "rope_store"
     (rope = dict(positions, cos_sin, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads, head_dim); returns q [M, H*D])."""
@@ -286,6 +286,9 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, epilo
     d = _lib.LinearDesc()
     d.x, d.w, d.m, d.n, d.k, d.x_row_stride = x.data_ptr(), weight.data_ptr(), m, n, k, x.stride(0)
     d.bias = bias.data_ptr() if bias is not None else None
+    if norm_folded:                                   # `weight` already carries the norm weight: w * diag(g)
+        assert norm_weight is None
+        d.norm_folded, d.norm_eps = 1, float(norm_eps)
     if norm_weight is not None:
         _require_gpu_bf16(norm_weight=norm_weight)
         assert norm_weight.numel() == k

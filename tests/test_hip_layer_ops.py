@@ -231,3 +231,26 @@ def test_argmax_rows(m, n):
     vals = x.float()
     exp = torch.tensor([int((vals[i] == vals[i].max()).nonzero()[0]) for i in range(m)])
     assert torch.equal(got, exp)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(32, 1152, 896, "none"), (32, 9728, 896, "silu_mul"), (9, 151936, 896, "none")])
+def test_fused_linear_folded_norm(m, n, k, epi):
+    """Folded RMSNorm (w := w*diag(g), row scale in the epilogue) against norm-then-project: same algebra, differs only by the
+    reference's two bf16 roundings of the normalised activations and the rounding of g*W."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(k + n)
+    x = (torch.randn(m, k, generator=g) * 3).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().cuda()
+    gw = (1 + 0.2 * torch.randn(k, generator=g)).bfloat16().cuda()
+    wf = (w.float() * gw.float().unsqueeze(0)).bfloat16().contiguous()
+    y = torch.nn.functional.linear(_ref_rms(x, gw, 1e-6).float(), w.float())
+    if epi == "silu_mul":
+        y = y.bfloat16()
+        ref = (torch.nn.functional.silu(y[:, :n // 2]) * y[:, n // 2:]).float()
+    else:
+        ref = y
+    out = ops.fused_linear(x, wf, norm_folded=True, norm_eps=1e-6, epilogue=epi).float()
+    torch.cuda.synchronize()
+    err = (out - ref).abs()
+    assert err.max() <= 0.03 * ref.abs().max()                      # bf16-level agreement of two valid roundings of the same math
+    assert (err / (ref.abs() + 0.05 * ref.abs().max())).mean() < 0.01
