@@ -158,6 +158,15 @@ int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t 
 /*   nvh_argmax_rows  greedy sampling (temperature 0; nanovllm/layers/sampler.py, bench_my.py:31): out[i] = argmax_j x[i, j],
  *                    int64, ties -> lowest index; x [n_rows, n] bf16, 16-byte aligned rows (row stride % 8 == 0). */
 int nvh_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t x_row_stride, int dtype, void* stream);
+/*   nvh_greedy_advance  the same arg-max fused with the host work between two decode steps, done on the device so a step is
+ *                    pure graph replay: append the token (engine/scheduler.py:99-110) and rebuild next step's decode metadata
+ *                    (engine/model_runner.py:244-269): tokens_log[row_steps[r], r] = tok; row_steps[r]++; input_ids[r] = tok;
+ *                    positions[r]++; context_lens[r]++; slot_mapping[r] = block_tables[r, (ctx-1)/bs]*bs + (ctx-1)%bs with the
+ *                    new ctx.  Rows whose context_lens is 0 (graph padding) are left untouched. */
+int nvh_greedy_advance(const void* logits, int n_rows, int n, int64_t logits_row_stride,
+                       int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                       const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                       int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, int dtype, void* stream);
 
 /*
  * Engine widening: weight-streaming linear layer for decode-sized batches, out = x . W^T (+ bias), m <= 64 rows.

@@ -271,7 +271,21 @@ int nvh_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t x_ro
     if (n_rows < 0 || n <= 0) { set_error("argmax_rows: bad shape"); return NVH_E_SHAPE; }
     if (x_row_stride % 8 || x_row_stride < n) { set_error("argmax_rows: row stride must be a multiple of 8 and >= n"); return NVH_E_STRIDE; }
     if (!aligned16(x)) { set_error("argmax_rows: x must be 16-byte aligned"); return NVH_E_ALIGN; }
-    return launch_argmax_rows(out, x, n_rows, n, x_row_stride, (hipStream_t)stream);
+    return launch_argmax_rows(out, x, n_rows, n, x_row_stride, AdvanceArgs{}, (hipStream_t)stream);
+}
+
+int nvh_greedy_advance(const void* logits, int n_rows, int n, int64_t logits_row_stride,
+                       int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                       const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                       int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, int dtype, void* stream) {
+    if (n_rows == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("greedy_advance: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!logits || !input_ids || !positions || !context_lens || !slot_mapping || !block_tables || !tokens_log || !row_steps) { set_error("greedy_advance: null pointer"); return NVH_E_NULL; }
+    if (n_rows < 0 || n <= 0 || block_size <= 0 || log_row_stride < n_rows) { set_error("greedy_advance: bad shape"); return NVH_E_SHAPE; }
+    if (logits_row_stride % 8 || logits_row_stride < n) { set_error("greedy_advance: logits row stride must be a multiple of 8 and >= n"); return NVH_E_STRIDE; }
+    if (!aligned16(logits)) { set_error("greedy_advance: logits must be 16-byte aligned"); return NVH_E_ALIGN; }
+    AdvanceArgs adv{input_ids, positions, context_lens, slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps};
+    return launch_argmax_rows(nullptr, logits, n_rows, n, logits_row_stride, adv, (hipStream_t)stream);
 }
 
 int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias, int m, int n, int k, int silu_inter,

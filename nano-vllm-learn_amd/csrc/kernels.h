@@ -49,7 +49,19 @@ int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, 
                        int64_t x_stride, int64_t out_stride, int64_t res_stride, hipStream_t stream);
 int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream);
 int max_rmsnorm_hidden(void);
-int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, hipStream_t stream);
+struct AdvanceArgs {             // all null: plain argmax
+    int64_t* input_ids;          // [rows] next step's input token
+    int64_t* positions;          // [rows] += 1
+    int32_t* context_lens;       // [rows] += 1 (rows with 0 are padding: untouched)
+    int32_t* slot_mapping;       // [rows] slot of the token the next step stores
+    const int32_t* block_tables; // [rows, width]
+    int64_t bt_stride;
+    int block_size;
+    int64_t* tokens_log;         // [steps, log_stride] generated tokens
+    int64_t log_stride;
+    int64_t* row_steps;          // [rows] tokens generated so far per row (log row index)
+};
+int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, const AdvanceArgs& adv, hipStream_t stream);
 
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_RESADD = 2, EPI_ROPE = 3 };   // == NVH_EPI_* in nvh_attn.h
 

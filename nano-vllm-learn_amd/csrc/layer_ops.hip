@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
 
 // Greedy sampling: argmax over each row of bf16 logits (nanovllm/layers/sampler.py at temperature 0 reduces to this).
 // One 1024-thread workgroup per row streams the row with 16-byte loads; ties resolve to the lowest index.
-__global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__ out, const uint16_t* __restrict__ x, int n, int64_t stride) {
+__global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__ out, const uint16_t* __restrict__ x, int n, int64_t stride,
+                                                            const AdvanceArgs adv) {
     __shared__ float lds_v[16];
     __shared__ int lds_i[16];
     const uint16_t* row = x + blockIdx.x * stride;
@@ -137,15 +138,30 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w)
             if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
-        out[blockIdx.x] = bidx;
+        if (out) out[blockIdx.x] = bidx;
+        if (adv.input_ids) {
+            // scheduler.postprocess (append the token) + prepare_decode for the NEXT step (engine/model_runner.py:244-269),
+            // on the device: this row's workgroup owns this row's metadata, so there is nothing to synchronise
+            const int row = blockIdx.x;
+            const int ctx = adv.context_lens[row];
+            if (ctx > 0) {                                         // padding rows (ctx 0, slot -1) stay as they are
+                adv.tokens_log[adv.row_steps[row] * adv.log_stride + row] = bidx;
+                adv.row_steps[row] += 1;
+                adv.input_ids[row] = bidx;
+                adv.positions[row] += 1;
+                adv.context_lens[row] = ctx + 1;
+                const int last = ctx;                              // index of the token the next step stores: new_ctx - 1
+                adv.slot_mapping[row] = adv.block_tables[row * adv.bt_stride + last / adv.block_size] * adv.block_size + last % adv.block_size;
+            }
+        }
     }
 }
 
 }  // namespace
 
-int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, hipStream_t stream) {
+int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, const AdvanceArgs& adv, hipStream_t stream) {
     if (n_rows == 0) return 0;
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_rows), dim3(1024), 0, stream, out, (const uint16_t*)x, n, stride);
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_rows), dim3(1024), 0, stream, out, (const uint16_t*)x, n, stride, adv);
     return check_launch("argmax_rows");
 }
 

@@ -150,6 +150,7 @@ class DecodeSession:
         self.slot_mapping = m["slot_mapping"].to(dev)
         self.tokens = torch.zeros(max_new_tokens + 1, b, dtype=torch.int64, device=dev)
         self.step_idx = torch.zeros((), dtype=torch.int64, device=dev)
+        self.row_steps = torch.zeros(b, dtype=torch.int64, device=dev)          # tokens generated per row (device-side log index)
         self.max_new_tokens = max_new_tokens
         self.steps_done = 0
         cfg = runner.cfg
@@ -180,13 +181,19 @@ class DecodeSession:
     def _step(self):
         set_context(False, slot_mapping=self.slot_mapping, context_lens=self.context_lens, block_tables=self.block_tables)
         hidden = self.runner.model(self.input_ids, self.positions)
-        self._advance(greedy_tokens(self.runner.model.compute_logits(hidden)))
+        logits = self.runner.model.compute_logits(hidden)
+        if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.stride(0) % 8 == 0:
+            # sampling + postprocess + next step's prepare_decode in ONE launch (nvh_greedy_advance)
+            ops.greedy_advance(logits, self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.block_tables,
+                               self.runner.block_size, self.tokens, self.row_steps)
+        else:
+            self._advance(greedy_tokens(logits))
         reset_context()
 
     @torch.inference_mode()
     def _capture(self):
         # capture must not disturb the live state: snapshot, warm up + capture, restore
-        live = (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx)
+        live = (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx, self.row_steps)
         saved = [t.clone() for t in live]
         try:
             stream = torch.cuda.Stream(device=self.runner.device)
@@ -196,6 +203,7 @@ class DecodeSession:
             torch.cuda.current_stream().wait_stream(stream)
             torch.cuda.synchronize()
             self.step_idx.zero_()
+            self.row_steps.zero_()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 self._step()
@@ -217,12 +225,12 @@ class DecodeSession:
 
     def rewind(self, seqs_state):
         """Reset the device metadata to a saved state (benchmark use: time the same context window repeatedly)."""
-        for t, s in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx), seqs_state):
+        for t, s in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx, self.row_steps), seqs_state):
             t.copy_(s)
-        self.steps_done = int(self.step_idx.item())
+        self.steps_done = int(self.row_steps.max().item())
 
     def state(self):
-        return [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx)]
+        return [t.clone() for t in (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx, self.row_steps)]
 
     def finish(self):
         """Copy generated tokens back into the host sequences (one device->host sync for the whole generation)."""

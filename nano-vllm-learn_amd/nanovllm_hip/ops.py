@@ -327,3 +327,19 @@ def argmax_rows(logits):
     rc = _lib.load().nvh_argmax_rows(out.data_ptr(), logits.data_ptr(), logits.shape[0], logits.shape[1], logits.stride(0), NVH_BF16, _stream())
     _lib.check(rc, "nvh_argmax_rows")
     return out
+
+
+def greedy_advance(logits, input_ids, positions, context_lens, slot_mapping, block_tables, block_size, tokens_log, row_steps):
+    """argmax_rows fused with the between-steps bookkeeping of a greedy decode session (nvh_greedy_advance): appends the
+    token to `tokens_log[row_steps[r], r]` and rewrites next step's input_ids / positions / context_lens / slot_mapping in place."""
+    _require_gpu_bf16(logits=logits)
+    _require_i32(context_lens=context_lens, slot_mapping=slot_mapping, block_tables=block_tables)
+    m = logits.shape[0]
+    assert logits.dim() == 2 and logits.stride(1) == 1 and block_tables.stride(1) == 1
+    for t in (input_ids, positions, tokens_log, row_steps):
+        assert t.dtype == torch.int64 and t.is_cuda
+    assert tokens_log.dim() == 2 and tokens_log.shape[1] >= m and tokens_log.stride(1) == 1
+    rc = _lib.load().nvh_greedy_advance(logits.data_ptr(), m, logits.shape[1], logits.stride(0), input_ids.data_ptr(), positions.data_ptr(),
+                                        context_lens.data_ptr(), slot_mapping.data_ptr(), block_tables.data_ptr(), block_tables.stride(0),
+                                        block_size, tokens_log.data_ptr(), tokens_log.stride(0), row_steps.data_ptr(), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_greedy_advance")
