@@ -345,3 +345,63 @@ def test_argument_errors_are_reported(ops):
         kc = torch.zeros(1, 256, 2, 96, dtype=torch.bfloat16, device="cuda")
         ops.flash_attn_with_kvcache(q, kc, kc, torch.ones(1, dtype=torch.int32, device="cuda"),
                                     torch.zeros(1, 1, dtype=torch.int32, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------ BASELINE.json configs
+def test_config3_long_context_block_table_stress(ops):
+    """BASELINE config 3: Qwen2-0.5B bs=64, contexts 2049..4096 (9..16 blocks per sequence, 16-wide table, shuffled ids).
+    Full-size run checked by properties (the numpy oracle would take minutes): (1) 8 sampled sequences against the oracle,
+    (2) relocating every block leaves the result bit-identical, (3) the -1 / 0 padding of dead table entries is irrelevant."""
+    B, H, KVH, D = 64, 14, 2, 64
+    q, kc, vc, ctxs, bt = _decode_case(303, B, H, KVH, D, 2049, 4096, width=16, pad=-1)
+    qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
+    base = ops.flash_attn_with_kvcache(qd, kd, vd, dev_i32(ctxs), dev_i32(bt), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    pick = [0, 7, 13, 21, 34, 47, 55, 63]
+    exp = O.paged_decode(q[pick].float().numpy(), kc.float().numpy(), vc.float().numpy(), ctxs[pick], bt[pick])
+    assert np.abs(base[pick].cpu().numpy() - exp).max() <= ATOL
+    bt0 = np.where(bt < 0, 0, bt).astype(np.int32)                      # graph-replay padding
+    again = ops.flash_attn_with_kvcache(qd, kd, vd, dev_i32(ctxs), dev_i32(bt0), out_dtype=torch.float32)
+    nb = kc.shape[0]
+    perm = torch.randperm(nb, generator=torch.Generator().manual_seed(9))
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(nb)
+    bt2 = np.where(bt >= 0, inv.numpy()[np.clip(bt, 0, None)], bt).astype(np.int32)
+    moved = ops.flash_attn_with_kvcache(qd, kd[perm].contiguous(), vd[perm].contiguous(), dev_i32(ctxs), dev_i32(bt2), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(base, again) and torch.equal(base, moved)
+
+
+@pytest.mark.parametrize("H,KVH,D", [(4, 1, 128), (3, 1, 128), (7, 1, 128), (2, 1, 64), (1, 1, 64)])
+def test_config4_tp_rank_shapes(ops, H, KVH, D):
+    """BASELINE config 4 (Qwen2-7B over 8 GPUs) and the Qwen2-0.5B TP=8 split: the per-rank head shapes tp_partition
+    produces (4/1, 3/1 at D=128; 2/1, 1/1 at D=64) plus the reference-rule tp=4 shape 7/1."""
+    q, kc, vc, ctxs, bt = _decode_case(400 + H, 6, H, KVH, D, 900, 1500)
+    exp = O.paged_decode(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), ctxs, bt)
+    o32 = ops.flash_attn_with_kvcache(q.cuda(), kc.cuda(), vc.cuda(), dev_i32(ctxs), dev_i32(bt), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert np.abs(o32.cpu().numpy() - exp).max() <= ATOL
+
+
+def test_config5_prefill_256x128(ops):
+    """BASELINE config 5: Qwen2-0.5B, 256 sequences x 128 tokens prefill (two scheduler batches of 128 sequences): one
+    batch at full size; 12 sampled sequences against the oracle, all rows finite, rows of a sequence independent of its
+    neighbours (re-running a sampled sequence alone reproduces its rows bit for bit)."""
+    H, KVH, D, S, B = 14, 2, 64, 128, 128
+    gen = torch.Generator().manual_seed(55)
+    T = B * S
+    qkv = torch.randn(T, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+    q = qkv[:, :H * D].view(T, H, D)
+    k = qkv[:, H * D:(H + KVH) * D].view(T, KVH, D)
+    v = qkv[:, (H + KVH) * D:].view(T, KVH, D)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device="cuda")
+    out = ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    cu1 = np.array([0, S], np.int32)
+    for i in (0, 1, 17, 31, 50, 63, 64, 77, 99, 101, 126, 127):
+        sl = slice(i * S, (i + 1) * S)
+        exp = O.prefill_varlen(q[sl].float().cpu().numpy(), k[sl].float().cpu().numpy(), v[sl].float().cpu().numpy(), cu1, cu1)
+        assert np.abs(out[sl].cpu().numpy() - exp).max() <= ATOL
+        alone = ops.flash_attn_varlen_func(q[sl], k[sl], v[sl], S, dev_i32(cu1), S, dev_i32(cu1), out_dtype=torch.float32)
+        assert torch.equal(alone, out[sl])
