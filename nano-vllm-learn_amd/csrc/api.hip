@@ -184,7 +184,7 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
         return NVH_E_STRIDE;
     }
     if (block_tables) {
-        if (block_size <= 0 || max_blocks <= 0 || bt_row_stride < max_blocks) {
+        if (block_size <= 0 || block_size % 64 != 0 || max_blocks <= 0 || bt_row_stride < max_blocks) {
             set_error("prefill_varlen: paged mode needs block_size/max_blocks/bt_row_stride");
             return NVH_E_SHAPE;
         }
@@ -206,6 +206,7 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
     a.bt_row_stride = bt_row_stride;
     a.scale_log2 = scale * kLog2e;
     a.out_f32 = out_dtype == NVH_F32;
+    a.stamps = g_stamps;
     return launch_prefill_varlen(a, (hipStream_t)stream);
 }
 
@@ -344,6 +345,7 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     a.norm_mode = d->norm_folded ? 2 : (d->norm_weight ? 1 : 0);
     a.positions = d->positions; a.cos_sin = d->cos_sin; a.k_cache = (uint16_t*)d->k_cache; a.v_cache = (uint16_t*)d->v_cache;
     a.slots = d->slot_mapping; a.h = d->h; a.kvh = d->kvh; a.hd = d->hd;
+    a.stamps = g_stamps;
     return launch_linear_small_m(a, (hipStream_t)stream);
 }
 

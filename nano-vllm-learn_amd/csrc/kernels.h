@@ -83,6 +83,7 @@ struct LinearArgs {
     uint16_t* v_cache;
     const int32_t* slots;
     int h, kvh, hd;              // ROPE: N == (h + 2*kvh) * hd
+    unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
 };
 int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
 
@@ -98,6 +99,7 @@ struct PrefillArgs {
     int64_t q_row_stride, k_row_stride, v_row_stride, bt_row_stride;
     float scale_log2;
     int out_f32;
+    unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
 };
 int launch_prefill_varlen(const PrefillArgs& a, hipStream_t stream);
 

@@ -5,21 +5,25 @@
 //                   bottom-right aligned causal mask; parity unpinned by the reference)
 //
 // Dense contraction -> MFMA (v_mfma_f32_16x16x32_bf16), flash-style online softmax, fp32 accumulate.
-// Workgroup = 4 waves = a tile of BM = 64 query rows of one (sequence, q head); wave w owns rows
-// 16w..16w+15.  K/V tiles of BN = 32 keys are staged through LDS (16-byte coalesced global loads,
-// rows padded by 16 B so the 16 lanes of a ds_read_b128 group land on 16 distinct bank slots).
+// Workgroup = 4 waves = a tile of BM = 64 query rows of one (sequence, q head); wave w owns rows 16w..16w+15.
+// K/V tiles of BN = 64 keys are staged through LDS by LDS-DMA (global_load_lds_dwordx4: one instruction = 1 KiB of
+// whole, coalesced key rows, no VGPR round trip), DOUBLE-BUFFERED: the DMA of tile i+1 is in flight while tile i is
+// computed; waves wait with a counted vmcnt and meet at raw s_barriers (a __syncthreads() would drain the prefetch).
+// LDS images are row-major [64 keys][D bf16]; the 16-byte chunk order inside a row is XOR-swizzled on the SOURCE
+// address so the MFMA operand reads are bank-conflict free (same images as the decode kernel).
 //
 // Orientation (what makes the softmax and the P operand lane-local):
 //   S^T = K Q^T     A = K rows (ds_read_b128), B = Q rows (registers, loaded once).
 //                   C layout: lane l, reg r holds S^T[key 4(l>>4)+r][query l&15]
-//                   -> a query's scores sit in 4 registers x 4 lane groups: row max/sum are 3 local ops
-//                   plus a 2-step cross-row reduction; the rescale factor is one scalar per lane.
-//   O^T = V^T P^T   B = P^T straight from the S^T accumulators of the two 16-key halves (k-slot j<4 ->
-//                   key 4g+j, j>=4 -> key 16+4g+j-4, g = l>>4); A = V^T in the SAME k order, produced by
-//                   ds_read_b64_tr_b16 (hardware transpose of a 4-key x 16-dim block) from row-major V.
-//                   P enters as hi + lo bf16 halves (two MFMAs per tile) so it keeps ~16 mantissa bits.
-//                   C layout: lane l, reg r holds O^T[dim 16t+4(l>>4)+r][query l&15] -> 4 contiguous
-//                   output dims per lane.
+//                   -> a query's scores sit in 4 registers x 4 lane groups: row max/sum are local ops plus a
+//                   2-step permlane reduction; the rescale factor is one scalar per lane.
+//   O^T = V^T P^T   B = P^T straight from the S^T accumulators of two 16-key tiles (k-slot j<4 -> key 4g+j,
+//                   j>=4 -> key 16+4g+j-4, g = l>>4); A = V^T in the SAME k order, produced by ds_read_b64_tr_b16
+//                   (hardware transpose of a 4-key x 16-dim block) from row-major V.  P enters as hi + lo bf16
+//                   halves (two MFMAs per tile) so it keeps ~16 mantissa bits (1e-3 parity bar at |o| ~ 3).
+//                   C layout: lane l, reg r holds O^T[dim 16t+4(l>>4)+r][query l&15] -> 4 contiguous dims per lane.
+// Causal structure: a workgroup only walks the key tiles its rows can see; a wave skips the MFMA work of tiles that lie
+// entirely above its own 16 rows' diagonal (it still takes part in the staging and the barriers).
 // Algorithmic flops per launch: sum_seq 4*D*H*(causal pairs); bytes: Tq*H*D*2*2 + Tk*KVH*D*2*2.
 #include "common.h"
 #include "kernels.h"
@@ -31,24 +35,61 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DNVH_STAMPS, tools/probes/stamp_prefill.py): wave 0 of every workgroup records the clock at
+// fixed points (slot k of 32 per workgroup).  Never compiled into the shipped library.
+#ifdef NVH_STAMPS
+#define PF_STAMP(k)                                                                                      \
+    do {                                                                                                 \
+        unsigned long long t_;                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (a.stamps && tid == 0 && (k) < 32)                                                            \
+            a.stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + (k)] = t_; \
+    } while (0)
+#else
+#define PF_STAMP(k) do {} while (0)
+#endif
+
 constexpr int BM = 64;      // query rows per workgroup
-constexpr int BN = 32;      // keys per LDS tile
+constexpr int BN = 64;      // keys per LDS tile
+
+// ds_read_b64_tr_b16 through inline asm: the builtin form makes hipcc wait vmcnt(0) before the read (it cannot prove the read
+// does not alias the LDS-DMA of the NEXT tile that is still in flight), which serialised the double buffer.  The caller
+// issues a batch of these, then `s_waitcnt lgkmcnt(0)` + a scheduling fence before the first use (guide rule 18).
+__device__ __forceinline__ u32x2 ds_read_tr16_b64_asm(uint32_t lds_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int LPT>
+__device__ __forceinline__ int chunk_swz(int row) {
+    return LPT == 8 ? ((row >> 1) & 7) : (row & 15);
+}
 
 template <int D, bool PAGED>
 __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a) {
-    constexpr int ROWB = D * 2 + 16;                 // padded LDS row, bytes
+    constexpr int ROWB = D * 2;                      // LDS row, bytes
+    constexpr int LPT = D / 8;                       // 16-byte chunks per row
+    constexpr int TPI = 64 / LPT;                    // rows per DMA instruction
+    constexpr int IMG = BN * ROWB;                   // one K (or V) image: 8 KiB (D=64) / 16 KiB (D=128)
+    constexpr int NI = IMG / 1024;                   // DMA instructions per image
+    constexpr int NIW = NI / 4;                      // ... per wave
     constexpr int STEPS = D / 32;                    // k-steps of the QK^T contraction
     constexpr int DT = D / 16;                       // 16-dim output tiles
-    constexpr int CPR = D / 8;                       // 16-byte chunks per row
-    __shared__ __attribute__((aligned(16))) unsigned char lds_k[BN * ROWB];
-    __shared__ __attribute__((aligned(16))) unsigned char lds_v[BN * ROWB];
+    constexpr int NT = BN / 16;                      // 16-key tiles of S^T per LDS tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * IMG];     // [buffer][K | V]
 
     const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
     const int q_beg = a.cu_q[b], q_end = a.cu_q[b + 1];
     const int k_beg = a.cu_k[b], k_end = a.cu_k[b + 1];
     const int sq = q_end - q_beg, sk = k_end - k_beg;
     const int q0 = qt * BM;
-    if (q0 >= sq) return;
+    if (q0 >= sq || sk <= 0) return;
     const int kh = head / (a.h / a.kvh);
     const int shift = sk - sq;                       // bottom-right alignment: query r sees keys <= r + shift
 
@@ -58,18 +99,21 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     const int lq = lane & 15;                        // query column of this lane
     const int lg = lane >> 4;                        // lane group: k-block of the operands / key rows of C
 
-    // ---- Q fragments (B operand of S^T): Q[row][32*step + 8*lg .. +8]
+    // ---- Q fragments (B operand of S^T): Q[row][32*step + 8*lg .. +8]; plain loads, retired before any DMA is issued
     const int my_q = q0 + wave * 16 + lq;            // query index inside the sequence
     const bool q_ok = my_q < sq;
     bf16x8 qf[STEPS];
     {
-        const uint16_t* qp = a.q + (int64_t)(q_beg + (q_ok ? my_q : 0)) * a.q_row_stride + (int64_t)head * D + lg * 8;
+        const uint16_t* qp = a.q + (int64_t)(q_beg + (q_ok ? my_q : sq - 1)) * a.q_row_stride + (int64_t)head * D + lg * 8;
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
-            u32x4 raw = q_ok ? *reinterpret_cast<const u32x4*>(qp + st * 32) : u32x4{0, 0, 0, 0};
-            qf[st] = *reinterpret_cast<bf16x8*>(&raw);
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + st * 32);
+            qf[st] = *reinterpret_cast<const bf16x8*>(&raw);
         }
     }
+    PF_STAMP(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PF_STAMP(1);
 
     f32x4 o[DT];
 #pragma unroll
@@ -79,98 +123,148 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     // keys any row of this workgroup can see: 0 .. min(sk, q0 + BM + shift) - 1
     int kv_end = q0 + BM + shift;
     if (kv_end > sk) kv_end = sk;
+    const int n_tiles = (kv_end + BN - 1) / BN;
     const int q_pos = my_q + shift;                  // last key this lane's query may see
+    const int wave_last_key = q0 + wave * 16 + 15 + shift;   // last key ANY row of this wave may see
 
-    for (int kv0 = 0; kv0 < kv_end; kv0 += BN) {
-        // ---- stage K and V tiles [BN][D] into LDS (zero rows past the sequence end)
-        __syncthreads();                             // previous tile fully consumed
+    // ---- staging: wave w issues DMA instructions w*NIW .. w*NIW+NIW-1 of the K image and of the V image
+    const int dp = lane % LPT, dr = lane / LPT;
+    auto stage = [&](int tile, int buf) {
+        unsigned char* kimg = lds + buf * 2 * IMG;
+        unsigned char* vimg = kimg + IMG;
+        const int kv0 = tile * BN;
+        int64_t blk_base = 0;
+        if constexpr (PAGED) {                       // BN divides block_size: one block per tile, wave-uniform id
+            const int blk = kv0 / a.block_size;
+            const int bid = a.block_tables[(int64_t)b * a.bt_row_stride + blk];
+            blk_base = ((int64_t)bid * a.block_size + (kv0 - blk * a.block_size)) * a.kvh;
+        }
 #pragma unroll
-        for (int c = tid; c < BN * CPR; c += 256) {
-            const int r = c / CPR, ch = c - r * CPR;
-            const int kidx = kv0 + r;
-            u32x4 kd = {0, 0, 0, 0}, vd = {0, 0, 0, 0};
-            if (kidx < sk) {
-                int64_t koff, voff;
-                if constexpr (PAGED) {
-                    const int blk = kidx / a.block_size;
-                    const int bid = a.block_tables[b * a.bt_row_stride + blk];
-                    koff = (((int64_t)bid * a.block_size + (kidx - blk * a.block_size)) * a.kvh + kh) * D + ch * 8;
-                    voff = koff;
-                } else {
-                    koff = (int64_t)(k_beg + kidx) * a.k_row_stride + (int64_t)kh * D + ch * 8;
-                    voff = (int64_t)(k_beg + kidx) * a.v_row_stride + (int64_t)kh * D + ch * 8;
+        for (int j = 0; j < NIW; ++j) {
+            const int ins = wave * NIW + j;
+            const int R = ins * TPI + dr;                                        // row of the tile
+            const int key = kv0 + R < sk ? kv0 + R : sk - 1;                     // rows past the sequence repeat its last key (masked)
+            const int ch = (dp ^ chunk_swz<LPT>(R)) * 8;
+            int64_t koff, voff;
+            if constexpr (PAGED) {
+                koff = (blk_base + (int64_t)(key - kv0) * a.kvh + kh) * D + ch;
+                voff = koff;
+            } else {
+                koff = (int64_t)(k_beg + key) * a.k_row_stride + (int64_t)kh * D + ch;
+                voff = (int64_t)(k_beg + key) * a.v_row_stride + (int64_t)kh * D + ch;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.k + koff),
+                                             (__attribute__((address_space(3))) void*)(kimg + ins * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v + voff),
+                                             (__attribute__((address_space(3))) void*)(vimg + ins * 1024), 16, 0, 0);
+        }
+    };
+
+    stage(0, 0);
+    const int vq = lq >> 2, vp = lq & 3;             // tr-read: lane 4q+p of its group addresses key row q, dims 4p..4p+3
+    for (int it = 0; it < n_tiles; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < n_tiles) {
+            stage(it + 1, buf ^ 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");       // tile `it` landed, tile it+1 in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        PF_STAMP(2 + 3 * it);
+        __builtin_amdgcn_s_barrier();                                            // every wave's share of tile `it` is in LDS
+        asm volatile("" ::: "memory");
+        PF_STAMP(3 + 3 * it);
+        const unsigned char* kimg = lds + buf * 2 * IMG;
+        const unsigned char* vimg = kimg + IMG;
+        const int kv0 = it * BN;
+        if (kv0 <= wave_last_key) {                                              // wave-uniform: tile not entirely above the diagonal
+            // ---- S^T for the four 16-key tiles
+            f32x4 sT[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int R = 16 * tt + lq;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + R * ROWB + (((4 * st + lg) ^ chunk_swz<LPT>(R)) * 16));
+                    sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
                 }
-                kd = *reinterpret_cast<const u32x4*>(a.k + koff);
-                vd = *reinterpret_cast<const u32x4*>(a.v + voff);
             }
-            *reinterpret_cast<u32x4*>(lds_k + r * ROWB + ch * 16) = kd;
-            *reinterpret_cast<u32x4*>(lds_v + r * ROWB + ch * 16) = vd;
-        }
-        __syncthreads();
-
-        // ---- S^T for the two 16-key halves
-        f32x4 st_acc[2];
+            // ---- online softmax in the log2 domain.  Masking only where it can matter: tiles that reach past this wave's
+            // first row's diagonal or past the sequence end (wave-uniform test); interior tiles skip the per-element work.
+            const bool need_mask = kv0 + BN - 1 > q0 + wave * 16 + shift || kv0 + BN > sk;
+            if (need_mask) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            st_acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-            for (int st = 0; st < STEPS; ++st) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds_k + (16 * t + lq) * ROWB + (st * 32 + lg * 8) * 2);
-                st_acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], st_acc[t], 0, 0, 0);
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + 16 * tt + 4 * lg + r;
+                        sT[tt][r] = (key <= q_pos && key < sk) ? sT[tt][r] : -INFINITY;
+                    }
+            }
+            float mx = fmaxf(fmaxf(sT[0][0], sT[0][1]), fmaxf(sT[0][2], sT[0][3]));
+#pragma unroll
+            for (int tt = 1; tt < NT; ++tt) mx = fmaxf(fmaxf(mx, fmaxf(sT[tt][0], sT[tt][1])), fmaxf(sT[tt][2], sT[tt][3]));
+            mx = max_xor16(mx);
+            mx = max_xor32(mx);
+            mx *= a.scale_log2;                                                  // scale > 0: max commutes with the scaling
+            const float m_new = fmaxf(m_run, mx);
+            // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            float psum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sT[tt][r] = fast_exp2(fmaf(sT[tt][r], a.scale_log2, -m_use));      // one FMA: scale and subtract the max
+                    psum += sT[tt][r];
+                }
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {              // some row's max moved: rescale (wave-uniform branch)
+                const float alpha = fast_exp2(m_run - m_use);                    // m_run = -inf -> 0
+                l_run *= alpha;
+#pragma unroll
+                for (int t = 0; t < DT; ++t) o[t] *= alpha;
+            }
+            l_run += psum;
+            m_run = m_new;
+            // ---- O^T += V^T P^T, 32 keys at a time, P as hi + lo bf16
+#pragma unroll
+            for (int hh = 0; hh < BN / 32; ++hh) {
+                bf16x8 p_hi, p_lo;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float pv = sT[2 * hh + (i >> 2)][i & 3];
+                    p_hi[i] = (__bf16)pv;
+                    p_lo[i] = (__bf16)(pv - (float)p_hi[i]);
+                }
+                const int R = 32 * hh + 4 * lg + vq;                             // chunk_swz(R) == chunk_swz(R + 16)
+                const uint32_t vrow = lds_offset(vimg + R * ROWB + (vp & 1) * 8);
+                const int swz = chunk_swz<LPT>(R);
+                u32x2 vlo[DT], vhi[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const uint32_t off = ((2 * t + (vp >> 1)) ^ swz) * 16;
+                    vlo[t] = ds_read_tr16_b64_asm(vrow + off);
+                    vhi[t] = ds_read_tr16_b64_asm(vrow + 16 * ROWB + off);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const u32x4 raw = {vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&raw);
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo, o[t], 0, 0, 0);
+                }
             }
         }
-        // ---- mask + online softmax (log2 domain)
-        float sv[8];
-        float mx = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kv0 + 16 * t + 4 * lg + r;
-                const bool ok = key <= q_pos && key < sk;
-                const float x = ok ? st_acc[t][r] * a.scale_log2 : -INFINITY;
-                sv[4 * t + r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = max_xor16(mx);
-        mx = max_xor32(mx);
-        const float m_new = fmaxf(m_run, mx);
-        // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;
-        const float alpha = fast_exp2(m_run - m_use);            // m_run = -inf -> 0
-        float psum = 0.f;
-        float pv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            pv[i] = fast_exp2(sv[i] - m_use);
-            psum += pv[i];
-        }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] *= alpha;
-        // P as hi + lo bf16 (~16 mantissa bits): a single bf16 P costs ~4e-3 abs at |o| ~ 3, over the 1e-3 parity bar
-        bf16x8 pf, pf_lo;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            pf[i] = (__bf16)pv[i];
-            pf_lo[i] = (__bf16)(pv[i] - (float)pf[i]);
-        }
-
-        // ---- O^T += V^T P^T
-#pragma unroll
-        for (int t = 0; t < DT; ++t) {
-            // lane 4q+p of its 16-lane group addresses key row (4*lg + q), dims 16t + 4p .. +3
-            const int vq = lq >> 2, vp = lq & 3;
-            const unsigned char* base = lds_v + (4 * lg + vq) * ROWB + (16 * t + 4 * vp) * 2;
-            const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base));
-            const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((bf16x4 __attribute__((address_space(3)))*)(base + 16 * ROWB));
-            const bf16x8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);   // whole-register concat, no repack
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[t], 0, 0, 0);
-            o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf_lo, o[t], 0, 0, 0);
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's LDS reads of buffer `buf` are done
+        PF_STAMP(4 + 3 * it);
+        __builtin_amdgcn_s_barrier();                                            // ... and everyone's: tile it+2 may overwrite it
+        asm volatile("" ::: "memory");
     }
 
+    PF_STAMP(31);
     // ---- finalise: total row sum over the 4 lane groups, normalise, store 4 contiguous dims per tile
     l_run = sum_xor16(l_run);
     l_run = sum_xor32(l_run);

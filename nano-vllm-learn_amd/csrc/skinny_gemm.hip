@@ -31,6 +31,17 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Diagnostic build only (-DNVH_STAMPS, tools/probes/stamp_gemm.py): per-wave clock stamps, 8 slots per wave, 8 waves per workgroup
+#ifdef NVH_STAMPS
+#define GM_STAMP(k)                                                                                             \
+    do {                                                                                                        \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                         \
+        if (a.stamps && lane == 0) a.stamps[((int64_t)blockIdx.x * 8 + wave) * 8 + (k)] = t_;                  \
+    } while (0)
+#else
+#define GM_STAMP(k) do {} while (0)
+#endif
+
 template <int MT, int WAVES, int EPI, int NORM>
 __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const LinearArgs a) {
     constexpr int NB = (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;           // weight row blocks per workgroup
@@ -46,8 +57,13 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, lg = lane >> 4;
+    GM_STAMP(0);
     // K is split among the waves in PIECES of 2 k-steps (64 elements = one 128-byte line of every weight row)
     const int npieces = a.K / 64;
+#ifdef NVH_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                           // kernel arguments have arrived
+    GM_STAMP(6);
+#endif
     const int pchunk = (npieces + WAVES - 1) / WAVES;
     const int ks0 = 2 * min(npieces, wave * pchunk);
     const int ks1 = 2 * min(npieces, (wave + 1) * pchunk);
@@ -149,6 +165,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
             for (int m = 0; m < MT; ++m) araw[i][m] = *reinterpret_cast<const u32x4*>(xrow[m] + ks * 32);
             if constexpr (NORM == 1) graw[i] = *reinterpret_cast<const u32x4*>(a.norm_w + ks * 32 + lg * 8);
         }
+        if (g0 == ks0) GM_STAMP(7);
 #pragma unroll
         for (int pi = 0; pi < GS / 2; ++pi) {                                  // piece pi of the group = k-steps g0+2pi, g0+2pi+1
             const int ks = g0 + 2 * pi < ks1 ? g0 + 2 * pi : ks1 - 2;
@@ -159,7 +176,9 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wdma[nb][hh] + ks * 32),
                                                      (__attribute__((address_space(3))) void*)(stage + ((pi * NB + nb) * 2 + hh) * 1024), 16, 0, 0);
         }
+        if (g0 == ks0) GM_STAMP(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g0 == ks0) GM_STAMP(2);
 #pragma unroll
         for (int i = 0; i < GS; ++i) {
             const bool live = g0 + i < ks1;
@@ -198,6 +217,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // LDS reads done before the next group's DMA overwrites
     }
+    GM_STAMP(3);
     // ---- reduce the K chunks of the waves
     if constexpr (NORM == 2) {
 #pragma unroll
@@ -212,6 +232,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
 #pragma unroll
         for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>((*reinterpret_cast<red_t*>(stage))[nb][m][lane]) = acc[nb][m];
     __syncthreads();
+    GM_STAMP(4);
     // value (m tile, lane, r) = product[16*mt + 4*(lane>>4) + r][column (lane&15) of each weight row block]
     for (int v = tid; v < MT * 256; v += WAVES * 64) {
         const int mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
@@ -276,6 +297,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_small_m_kernel(const Linear
             out[(int64_t)row * a.out_stride + n0 + c] = (__bf16)y;
         }
     }
+    GM_STAMP(5);
 }
 
 template <int MT, int EPI, int NORM>
