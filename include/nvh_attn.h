@@ -217,8 +217,20 @@ typedef struct nvh_linear_desc {
     const int32_t* slot_mapping;
     int32_t h, kvh, hd;
     int32_t norm_folded;
+    /* streaming form (csrc/linear_stream.hip), all optional: */
+    int32_t x_packed;               /* x is in MFMA-fragment order [ceil(m/16)][k/32][64][8] (nvh_pack_index); x_row_stride unused */
+    void* out_packed;               /* NULL or: the epilogue also writes its bf16 result in fragment order
+                                       ([ceil(m/16)][cols/32][64][8], cols = n, or silu_inter for SILU_MUL); `out` may then be
+                                       NULL for NONE / SILU_MUL */
+    void* workspace;                /* NULL or nvh_linear_small_m_workspace() bytes, ZERO-FILLED once by the caller (the
+                                       kernel leaves its tickets zero); needed when k > 1024: K is then split over
+                                       workgroups and the last-arriving one sums the partials in a fixed order */
+    size_t workspace_bytes;
 } nvh_linear_desc;
 int nvh_linear_small_m_ex(const nvh_linear_desc* desc, int dtype, void* stream);
+size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue);
+/* offset (in elements) of activation element (row, col) of an [m, cols] matrix in fragment order */
+int64_t nvh_pack_index(int row, int col, int cols);
 
 #ifdef __cplusplus
 }

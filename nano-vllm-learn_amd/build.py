@@ -18,14 +18,14 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nanovllm_hip", "lib")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libnvh_attn.so")
-SOURCES = ["api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip"]
+SOURCES = ["api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip"]
 HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "nvh_attn.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-Wall", "-Wno-unused-function", "-Wno-unused-command-line-argument"]
 # rope_store.hip must round RoPE's products and sums separately (bit parity with the reference's elementwise fp32 ops);
 # HIP's default backend contraction ignores the source pragma, so that file is built with contraction off.
-FILE_FLAGS = {"rope_store.hip": ["-ffp-contract=off"], "skinny_gemm.hip": ["-ffp-contract=off"]}   # its RoPE epilogue too
+FILE_FLAGS = {"rope_store.hip": ["-ffp-contract=off"], "skinny_gemm.hip": ["-ffp-contract=off"], "linear_stream.hip": ["-ffp-contract=off"]}   # its RoPE epilogue too
 
 
 def _digest():

@@ -310,7 +310,8 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     if (!d) { set_error("linear_small_m_ex: null descriptor"); return NVH_E_NULL; }
     if (d->m == 0) return 0;
     if (dtype != NVH_BF16) { set_error("linear_small_m_ex: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
-    if (!d->out || !d->x || !d->w) { set_error("linear_small_m_ex: null pointer"); return NVH_E_NULL; }
+    const bool out_optional = d->out_packed && (d->epilogue == NVH_EPI_NONE || d->epilogue == NVH_EPI_SILU_MUL);
+    if ((!d->out && !out_optional) || !d->x || !d->w) { set_error("linear_small_m_ex: null pointer"); return NVH_E_NULL; }
     if (d->m < 0 || d->m > 64 || d->n <= 0 || d->k <= 0 || d->k % 64 || d->n % 16) {
         set_error("linear_small_m_ex: m=%d (<=64) n=%d (%%16) k=%d (%%64)", d->m, d->n, d->k);
         return NVH_E_SHAPE;
@@ -335,7 +336,9 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
             break;
         default: set_error("linear_small_m_ex: unknown epilogue %d", d->epilogue); return NVH_E_SHAPE;
     }
-    if (d->x_row_stride % 8 || d->x_row_stride < d->k || d->out_row_stride < out_cols) { set_error("linear_small_m_ex: bad row strides"); return NVH_E_STRIDE; }
+    if ((!d->x_packed && (d->x_row_stride % 8 || d->x_row_stride < d->k)) || (d->out && d->out_row_stride < out_cols)) { set_error("linear_small_m_ex: bad row strides"); return NVH_E_STRIDE; }
+    if (d->out_packed && (!aligned16(d->out_packed) || out_cols % 32)) { set_error("linear_small_m_ex: out_packed needs 16-byte alignment and cols %% 32 == 0"); return NVH_E_ALIGN; }
+    if (d->workspace && !aligned16(d->workspace)) { set_error("linear_small_m_ex: workspace must be 16-byte aligned"); return NVH_E_ALIGN; }
     if (!aligned16(d->x) || !aligned16(d->w) || (d->norm_weight && !aligned16(d->norm_weight))) { set_error("linear_small_m_ex: x, w, norm_weight must be 16-byte aligned"); return NVH_E_ALIGN; }
     LinearArgs a;
     a.out = d->out; a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = (const uint16_t*)d->bias;
@@ -346,7 +349,18 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     a.positions = d->positions; a.cos_sin = d->cos_sin; a.k_cache = (uint16_t*)d->k_cache; a.v_cache = (uint16_t*)d->v_cache;
     a.slots = d->slot_mapping; a.h = d->h; a.kvh = d->kvh; a.hd = d->hd;
     a.stamps = g_stamps;
+    a.x_packed = d->x_packed; a.out_packed = (uint16_t*)d->out_packed; a.ws_raw = d->workspace; a.ws_bytes = d->workspace_bytes;
+    a.ws = nullptr; a.counters = nullptr; a.ksplit = 1; a.tiles = 0;
+    const int rc = launch_linear_stream(a, (hipStream_t)stream);
+    if (rc != -100) return rc;
+    if (d->x_packed || d->out_packed) {
+        set_error("linear_small_m_ex: packed activations need the streaming kernel (k %% 64 == 0, no exact-norm prologue, workspace when k > 1024)");
+        return NVH_E_SHAPE;
+    }
     return launch_linear_small_m(a, (hipStream_t)stream);
 }
+
+size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue) { return linear_stream_workspace_bytes(m, n, k, epilogue); }
+int64_t nvh_pack_index(int row, int col, int cols) { return pack_index(row, col, cols); }
 
 }  // extern "C"

@@ -84,8 +84,25 @@ struct LinearArgs {
     const int32_t* slots;
     int h, kvh, hd;              // ROPE: N == (h + 2*kvh) * hd
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
+    // ---- streaming kernel only (linear_stream.hip)
+    int x_packed;                // x is in MFMA-fragment order: [ceil(M/16)][K/32][64 lanes][8] bf16 (see pack_index)
+    uint16_t* out_packed;        // nullable: the epilogue also writes its bf16 result in fragment order, for the next GEMM
+    void* ws_raw;                // caller's workspace (counters + partials), ws_bytes long; split into the two fields below
+    size_t ws_bytes;
+    float* ws;                   // split-K partials [tile][split][NB*MT*256 + MT*16] fp32 (null: no split-K)
+    unsigned* counters;          // [tiles] arrival tickets, zero before the launch, left zero by it
+    int ksplit;                  // workgroups sharing one tile's K range (>= 1)
+    int tiles;                   // weight row tiles (16 rows, or 16 + 16 partner rows for SILU / ROPE)
 };
 int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
+int launch_linear_stream(const LinearArgs& a, hipStream_t stream);   // linear_stream.hip; returns -100 when the shape is not its own
+size_t linear_stream_workspace_bytes(int m, int n, int k, int epi);
+
+// element (row, col) of an [M, C] activation in MFMA-fragment order (A operand of v_mfma_f32_16x16x32_bf16):
+// [row / 16][col / 32][lane = 16 * ((col / 8) % 4) + row % 16][col % 8]
+__host__ __device__ inline int64_t pack_index(int row, int col, int cols) {
+    return ((((int64_t)(row >> 4) * (cols >> 5) + (col >> 5)) * 64 + (((col >> 3) & 3) << 4) + (row & 15)) << 3) + (col & 7);
+}
 
 struct PrefillArgs {
     void* out;                   // [Tq, H, D]

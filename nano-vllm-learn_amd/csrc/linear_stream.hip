@@ -1,0 +1,447 @@
+// Weight-streaming linear layer for decode-sized batches (M <= 64 rows), single-pass form — engine widening around the
+// attention call, not part of the attention parity bar.  Same contract as skinny_gemm.hip (prologue NORM 0 / 2, the four
+// epilogues); that file stays the general fallback (exact-norm prologue, K loops, no workspace).
+//
+// Why a second kernel: stamps of the loop kernel (tools/probes/stamp_gemm.py, profiles/r01_gemm_phase_stamps.txt) show a
+// decode GEMM is a chain of latencies, not a bandwidth problem: 0.5 us kernel arguments, 1.2 us (p90 4.5) ISSUING the x
+// operand as fragment-shaped loads (16 rows x 64 B per instruction: four rows per lane quad, a quarter of the address rate),
+// 1.2 us issuing the W DMA queued behind them, 1.3 us landing, then one such round per K group (down_proj: five rounds on 56
+// workgroups).  This kernel makes the chain as short as the hardware allows:
+//   * every wave owns at most PMAX = 4 pieces (64 K-elements each) of ONE weight tile, so the whole K range is in flight at
+//     once; long K is split over workgroups (grid.y = ksplit) and the tile's LAST-ARRIVING workgroup sums the fp32 partials
+//     in split order (deterministic) and runs the epilogue: no second launch, no float atomics.
+//   * W DMA is issued first (addresses need only the kernel arguments), x second.
+//   * x can arrive PACKED in MFMA-fragment order (kernels.h pack_index): one coalesced 1 KiB load per fragment; the
+//     epilogues can write that layout for the next GEMM (out_packed), so inside the fused decoder layer activations never
+//     take the quarter-rate path.
+//   * the folded-norm row sums use v_dot2_f32_bf16 on the packed pairs; the residual operand of RESADD is fetched while W
+//     is in flight.
+//   * wide N (LM head): a workgroup walks several tiles with x held in registers and the next tile's W DMA in flight
+//     (MULTI), so x is fetched once per workgroup instead of once per tile.
+// Hand-off (split-K), fence-free form: the partials are stored write-through (relaxed agent-scope atomic stores = `sc1`
+// stores), every storing wave drains them (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 takes the ticket (relaxed agent
+// atomic add); the workgroup whose add came last reads all partials with `sc1` loads (relaxed agent-scope atomic loads) after
+// a workgroup barrier the ticket holder joins.  A release/acquire fence pair here cost 4-5 us per launch (whole-L2
+// write-back + invalidate under 280 workgroups; profiles/r01_gemm_phase_stamps.txt).
+#include "common.h"
+#include "kernels.h"
+
+namespace nvh {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int SW = 4;                          // waves per workgroup
+constexpr int PMAX = 4;                        // pieces (2 k-steps = 64 K-elements = one 128-byte line per weight row) per wave
+
+#ifdef NVH_STAMPS
+#define LS_STAMP(k)                                                                                                        \
+    do {                                                                                                                   \
+        const unsigned long long t_ = __builtin_amdgcn_s_memrealtime();                                                    \
+        if (a.stamps && lane == 0) a.stamps[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave) * 8 + (k)] = t_;   \
+    } while (0)
+#else
+#define LS_STAMP(k) do {} while (0)
+#endif
+
+// write-through store / cache-bypassing load of one float (compile to global_store_dword / global_load_dword with sc1)
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// leave the newest `np` pieces' DMA (np * PER instructions) in flight
+template <int PER>
+__device__ __forceinline__ void wait_all_but_pieces(int np) {
+    switch (np) {
+        case 0: wait_vm<0>(); break;
+        case 1: wait_vm<PER>(); break;
+        case 2: wait_vm<2 * PER>(); break;
+        case 3: wait_vm<3 * PER>(); break;
+        default: wait_vm<4 * PER>(); break;
+    }
+}
+
+template <int MT, int EPI, int NORM, bool XPACK, bool MULTI>
+__global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs a) {
+    constexpr int NB = (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;           // weight row blocks per tile
+    constexpr int NBUF = MULTI ? 2 : 1;
+    constexpr int STAGE = NB * PMAX * 2048;                                    // W staging bytes per wave per buffer
+    constexpr int PSTRIDE = NB * MT * 256 + MT * 16;                           // floats per (tile, split) partial record
+    static_assert(NB * MT * 1024 <= STAGE, "the wave's reduction tile aliases the staging buffer it has just consumed");
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[SW * NBUF * STAGE + SW * MT * 16 * 4 + 16];
+    typedef float red_t[NB][MT][64][4];
+    typedef float ss_t[MT][16];
+    ss_t* const lds_ss = reinterpret_cast<ss_t*>(lds_raw + SW * NBUF * STAGE);
+    unsigned* const lds_ticket = reinterpret_cast<unsigned*>(lds_raw + SW * NBUF * STAGE + SW * MT * 16 * 4);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, lg = lane >> 4;
+    LS_STAMP(0);
+
+    // ---- this wave's K range: the tile's pieces are split over the ksplit workgroups, then over the 4 waves
+    const int P = a.K / 64;
+    const int split = blockIdx.y;
+    const int wp0 = (int)((int64_t)P * split / a.ksplit), wp1 = (int)((int64_t)P * (split + 1) / a.ksplit);
+    const int p0 = __builtin_amdgcn_readfirstlane(wp0 + (wp1 - wp0) * wave / SW);
+    const int np = __builtin_amdgcn_readfirstlane(wp0 + (wp1 - wp0) * (wave + 1) / SW - p0);      // 0..PMAX (host guarantees)
+    const int KS = a.K / 32;
+    const int tile_first = MULTI ? (int)((int64_t)a.tiles * blockIdx.x / gridDim.x) : (int)blockIdx.x;
+    const int tile_end = MULTI ? (int)((int64_t)a.tiles * (blockIdx.x + 1) / gridDim.x) : tile_first + 1;
+
+    // ---- W DMA: one instruction = 8 rows x 128 B (one whole line per row); LDS image of a piece = [16 rows][128 B] with the
+    // 16-byte chunk order XOR-swizzled on the SOURCE so the operand reads are conflict free (as skinny_gemm.hip)
+    const int dr = lane >> 3, dp = lane & 7;
+    const int rswz = (lq >> 1) & 7;
+    auto tile_rows = [&](int tile, int& n0, int& n1, int& head, int& hi0) {
+        n1 = 0; head = 0; hi0 = 0;
+        if constexpr (EPI == EPI_ROPE) {
+            const int per_head = a.hd / 32;                          // tiles per head: columns i and i + D/2 together
+            head = tile / per_head;
+            hi0 = 16 * (tile % per_head);
+            n0 = head * a.hd + hi0;
+            n1 = n0 + a.hd / 2;
+        } else {
+            n0 = tile * 16;
+            if constexpr (EPI == EPI_SILU) n1 = a.inter + n0;
+        }
+    };
+    auto issue_w = [&](int tile, int buf) {
+        int n0, n1, head, hi0;
+        tile_rows(tile, n0, n1, head, hi0);
+        unsigned char* const stage = lds_raw + (wave * NBUF + buf) * STAGE;
+#pragma unroll
+        for (int pi = 0; pi < PMAX; ++pi) {
+            if (pi < np) {                                           // wave-uniform
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int row = 8 * hh + dr;
+                        const uint16_t* src = a.w + (int64_t)((nb == 0 ? n0 : n1) + row) * a.K + (p0 + pi) * 64 + (dp ^ ((row >> 1) & 7)) * 8;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                         (__attribute__((address_space(3))) void*)(stage + ((pi * NB + nb) * 2 + hh) * 1024), 16, 0, 0);
+                    }
+            }
+        }
+    };
+
+    issue_w(tile_first, 0);
+    LS_STAMP(1);
+
+    // ---- x fragments of this wave's K range, kept in registers for every tile of the workgroup
+    u32x4 araw[2 * PMAX][MT];
+#pragma unroll
+    for (int pi = 0; pi < PMAX; ++pi) {
+        if (pi < np) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int ks = 2 * (p0 + pi) + j;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    if constexpr (XPACK) {
+                        araw[2 * pi + j][m] = *reinterpret_cast<const u32x4*>(a.x + (((int64_t)m * KS + ks) * 64 + lane) * 8);
+                    } else {
+                        const int r = 16 * m + lq;                   // rows past M repeat the last row; discarded
+                        araw[2 * pi + j][m] = *reinterpret_cast<const u32x4*>(a.x + (int64_t)(r < a.M ? r : a.M - 1) * a.x_stride + ks * 32 + lg * 8);
+                    }
+                }
+            }
+        }
+    }
+    // residual operand of RESADD for the elements this thread finishes (value v = tid + 256 j, see below)
+    uint16_t resid[MT];
+    if constexpr (EPI == EPI_RESADD && !MULTI) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + 256 * j, l = (v >> 2) & 63;
+            const int row = 16 * (v >> 8) + 4 * (l >> 4) + (v & 3);
+            resid[j] = row < a.M ? reinterpret_cast<const uint16_t*>(a.out)[(int64_t)row * a.out_stride + tile_first * 16 + (l & 15)] : (uint16_t)0;
+        }
+    }
+    LS_STAMP(2);
+
+    float ss2[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) ss2[m] = 0.f;
+    bool ss_done = false;
+
+    for (int tile = tile_first, buf = 0; tile < tile_end; ++tile, buf ^= (NBUF - 1)) {
+        if (MULTI && tile + 1 < tile_end) {
+            issue_w(tile + 1, buf ^ 1);
+            wait_all_but_pieces<NB * 2>(np);
+        } else {
+            wait_vm<0>();
+        }
+        if (tile == tile_first) LS_STAMP(3);
+        unsigned char* const stage = lds_raw + (wave * NBUF + buf) * STAGE;
+        f32x4 acc[NB][MT];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[nb][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pi = 0; pi < PMAX; ++pi) {
+            if (pi < np) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    u32x4 braw[NB];
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        braw[nb] = *reinterpret_cast<const u32x4*>(stage + (pi * NB + nb) * 2048 + lq * 128 + (((4 * j + lg) ^ rswz) * 16));
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) {
+                        const u32x4 av = araw[2 * pi + j][m];
+                        if constexpr (NORM == 2) {
+                            if (!ss_done) {
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) ss2[m] = dot2_bf16(av[w], av[w], ss2[m]);
+                            }
+                        }
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(&av);
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[nb][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, *reinterpret_cast<const bf16x8*>(&braw[nb]), acc[nb][m], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // this wave's staging reads are done: reuse the buffer
+        if (tile == tile_first) LS_STAMP(4);
+        // ---- reduce the 4 waves through LDS (the wave's reduction tile aliases the staging buffer it has just consumed)
+        if constexpr (NORM == 2) {
+            if (!ss_done) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    float t = sum_xor16(ss2[m]);                              // fold the 4 lane groups (k sub-blocks) of the row
+                    t = sum_xor32(t);
+                    if (lg == 0) lds_ss[wave][m][lq] = t;
+                }
+                ss_done = true;
+            }
+        }
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) *reinterpret_cast<f32x4*>((*reinterpret_cast<red_t*>(stage))[nb][m][lane]) = acc[nb][m];
+        __syncthreads();
+        int n0, n1, head, hi0;
+        tile_rows(tile, n0, n1, head, hi0);
+        // value v = (m tile, lane, r): product[16 * mt + 4 * (lane >> 4) + r][column lane & 15 of each weight row block]
+        float s[MT][NB], rowss[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + 256 * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                s[j][nb] = 0.f;
+#pragma unroll
+                for (int w = 0; w < SW; ++w) s[j][nb] += (*reinterpret_cast<const red_t*>(lds_raw + (w * NBUF + buf) * STAGE))[nb][mt][l][r];
+            }
+            rowss[j] = 0.f;
+            if constexpr (NORM == 2) {
+#pragma unroll
+                for (int w = 0; w < SW; ++w) rowss[j] += lds_ss[w][mt][4 * (l >> 4) + r];
+            }
+        }
+        if (a.ksplit > 1) {
+            // ---- split-K: publish the partial, take a ticket; the last arriver sums all partials in split order
+            float* const part = a.ws + ((int64_t)tile * a.ksplit + split) * PSTRIDE;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) st_sc1(part + nb * MT * 256 + tid + 256 * j, s[j][nb]);
+            }
+            if constexpr (NORM == 2) {
+                if (tid < MT * 16) {
+                    float t = 0.f;
+#pragma unroll
+                    for (int w = 0; w < SW; ++w) t += lds_ss[w][tid >> 4][tid & 15];
+                    st_sc1(part + NB * MT * 256 + tid, t);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const unsigned old = __hip_atomic_fetch_add(&a.counters[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == (unsigned)a.ksplit - 1)
+                    __hip_atomic_store(&a.counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+                *lds_ticket = old;
+            }
+            __syncthreads();
+            if (*lds_ticket != (unsigned)a.ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
+            const float* const base = a.ws + (int64_t)tile * a.ksplit * PSTRIDE;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int v = tid + 256 * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) s[j][nb] = 0.f;
+                rowss[j] = 0.f;
+                for (int sp0 = 0; sp0 < a.ksplit; sp0 += 8) {
+                    float tmp[8][NB + 1];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int sp = sp0 + i < a.ksplit ? sp0 + i : a.ksplit - 1;
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb) tmp[i][nb] = ld_sc1(base + (int64_t)sp * PSTRIDE + nb * MT * 256 + v);
+                        tmp[i][NB] = NORM == 2 ? ld_sc1(base + (int64_t)sp * PSTRIDE + NB * MT * 256 + mt * 16 + 4 * (l >> 4) + r) : 0.f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        if (sp0 + i < a.ksplit) {
+#pragma unroll
+                            for (int nb = 0; nb < NB; ++nb) s[j][nb] += tmp[i][nb];
+                            rowss[j] += tmp[i][NB];
+                        }
+                    }
+                }
+            }
+        }
+        if (tile == tile_first) LS_STAMP(5);
+        // ---- epilogue
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + 256 * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+            const int row = 16 * mt + 4 * (l >> 4) + r;
+            if (row >= a.M) continue;
+            const int c = l & 15;
+            float y[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) y[nb] = s[j][nb];
+            if constexpr (NORM == 2) {                                 // x.(g*W)^T * rsqrt(mean(x^2)+eps) == RMSNorm(x).W^T without the two bf16 roundings
+                const float inv_row = rsqrtf(rowss[j] / a.K + a.norm_eps);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) y[nb] *= inv_row;
+            }
+            __bf16* const out = reinterpret_cast<__bf16*>(a.out);
+            if constexpr (EPI == EPI_SILU) {
+                const float g = (float)(__bf16)y[0], u = (float)(__bf16)y[1];          // the projection output is bf16 in the reference
+                const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
+                if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
+                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.inter)] = __builtin_bit_cast(uint16_t, o);
+            } else if constexpr (EPI == EPI_RESADD) {
+                __bf16* p = out + (int64_t)row * a.out_stride + n0 + c;
+                const float old = MULTI ? (float)*p : (float)__builtin_bit_cast(__bf16, resid[j]);
+                const __bf16 o = (__bf16)(y[0] + old);
+                *p = o;
+                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.N)] = __builtin_bit_cast(uint16_t, o);
+            } else if constexpr (EPI == EPI_ROPE) {
+                float x1 = y[0], x2 = y[1];
+                if (a.bias) {
+                    x1 += (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]);
+                    x2 += (float)__builtin_bit_cast(__bf16, a.bias[n1 + c]);
+                }
+                x1 = (float)(__bf16)x1;                                    // the projection output is bf16 in the reference
+                x2 = (float)(__bf16)x2;
+                const int i = hi0 + c;                                     // index inside the half head
+                float y1 = x1, y2 = x2;
+                if (head < a.h + a.kvh) {                                  // q or k head: rotate (products and sums rounded separately)
+                    const float* cs = a.cos_sin + a.positions[row] * a.hd;
+                    const float co = cs[i], si = cs[a.hd / 2 + i];
+                    const float p1 = x1 * co, p2 = x2 * si, p3 = x2 * co, p4 = x1 * si;
+                    y1 = p1 - p2;
+                    y2 = p3 + p4;
+                }
+                if (head < a.h) {
+                    __bf16* q = out + (int64_t)row * a.out_stride + head * a.hd + i;
+                    q[0] = (__bf16)y1;
+                    q[a.hd / 2] = (__bf16)y2;
+                } else {
+                    const int slot = a.slots[row];
+                    if (slot >= 0) {
+                        const bool is_v = head >= a.h + a.kvh;
+                        __bf16* dst = reinterpret_cast<__bf16*>(is_v ? a.v_cache : a.k_cache) +
+                                      ((int64_t)slot * a.kvh + (head - a.h - (is_v ? a.kvh : 0))) * a.hd + i;
+                        dst[0] = (__bf16)y1;
+                        dst[a.hd / 2] = (__bf16)y2;
+                    }
+                }
+            } else {
+                const __bf16 o = (__bf16)(y[0] + (a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f));
+                if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
+                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.N)] = __builtin_bit_cast(uint16_t, o);
+            }
+        }
+        if (MULTI) __syncthreads();                                   // reduction tiles read before the next-but-one DMA lands on them
+    }
+    LS_STAMP(6);
+}
+
+template <int MT, int EPI, int NORM, bool XPACK>
+int launch_x(const LinearArgs& a, hipStream_t stream) {
+    const bool multi = EPI == EPI_NONE && a.ksplit == 1 && a.tiles > 1024;
+    if (multi) {
+        if constexpr (EPI == EPI_NONE) {
+            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, a);
+        }
+    } else {
+        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
+    }
+    return check_launch("linear_stream");
+}
+
+template <int MT, int EPI>
+int launch_e(const LinearArgs& a, hipStream_t stream) {
+    if (a.norm_mode == 2) return a.x_packed ? launch_x<MT, EPI, 2, true>(a, stream) : launch_x<MT, EPI, 2, false>(a, stream);
+    return a.x_packed ? launch_x<MT, EPI, 0, true>(a, stream) : launch_x<MT, EPI, 0, false>(a, stream);
+}
+
+template <int MT>
+int launch_mt(const LinearArgs& a, hipStream_t stream) {
+    switch (a.epi) {
+        case EPI_NONE: return launch_e<MT, EPI_NONE>(a, stream);
+        case EPI_SILU: return launch_e<MT, EPI_SILU>(a, stream);
+        case EPI_RESADD: return launch_e<MT, EPI_RESADD>(a, stream);
+        case EPI_ROPE: return launch_e<MT, EPI_ROPE>(a, stream);
+    }
+    return -100;
+}
+
+int tiles_of(int n, int inter, int h, int kvh, int hd, int epi) {
+    if (epi == EPI_ROPE) return (h + 2 * kvh) * (hd / 32);
+    if (epi == EPI_SILU) return inter / 16;
+    return n / 16;
+}
+
+}  // namespace
+
+// counters [tiles] (rounded to 256 B) then partial records [tiles][ksplit][NB*MT*256 + MT*16] fp32; 0 when K needs no split
+size_t linear_stream_workspace_bytes(int m, int n, int k, int epi) {
+    const int pieces = k / 64, ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);
+    if (ksplit <= 1) return 0;
+    const int nb = (epi == EPI_SILU || epi == EPI_ROPE) ? 2 : 1, mt = (m + 15) / 16;
+    const int tiles = nb == 2 ? n / 32 : n / 16;
+    return (((size_t)tiles * 4 + 255) / 256) * 256 + (size_t)tiles * ksplit * (nb * mt * 256 + mt * 16) * 4;
+}
+
+// Returns -100 when the call is not this kernel's (the caller falls back to skinny_gemm.hip's loop kernel).
+int launch_linear_stream(const LinearArgs& a_in, hipStream_t stream) {
+    LinearArgs a = a_in;
+    if (a.M == 0) return 0;
+    if (a.norm_mode == 1 || a.K % 64 != 0 || a.M > 64) return -100;
+    a.tiles = tiles_of(a.N, a.inter, a.h, a.kvh, a.hd, a.epi);
+    const int pieces = a.K / 64;
+    a.ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);
+    if (a.ksplit > 1) {
+        const size_t counters_bytes = (((size_t)a.tiles * 4 + 255) / 256) * 256;
+        if (!a.ws_raw || a.ws_bytes < linear_stream_workspace_bytes(a.M, a.N, a.K, a.epi)) return -100;
+        a.counters = reinterpret_cast<unsigned*>(a.ws_raw);
+        a.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.ws_raw) + counters_bytes);
+    }
+    switch ((a.M + 15) / 16) {
+        case 1: return launch_mt<1>(a, stream);
+        case 2: return launch_mt<2>(a, stream);
+        case 3: return launch_mt<3>(a, stream);
+        case 4: return launch_mt<4>(a, stream);
+    }
+    return -100;
+}
+
+}  // namespace nvh

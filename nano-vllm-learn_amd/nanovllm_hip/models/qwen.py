@@ -290,36 +290,62 @@ class QwenForCausalLM(nn.Module):
                     head=fold(head, self.norm.weight))
         return self._folded
 
+    def _decode_buffers(self, m, device):
+        """Per batch-size scratch of the fused decode path, allocated once (before graph capture) and reused: the residual
+        stream and the MLP activation in MFMA-fragment order (what the streaming GEMM reads at full address rate), and the
+        zero-filled split-K workspace (tickets return to zero after every launch)."""
+        from .. import ops
+        key = (m, str(device))
+        bufs = self.__dict__.setdefault("_decode_bufs", {})
+        if key not in bufs:
+            cfg, rows = self.cfg, ((m + 15) // 16) * 16
+            inter = self.layers[0].mlp.down_proj.weight.shape[1]
+            need = max(ops.linear_workspace_bytes(m, cfg.hidden_size, inter, "residual_add"),
+                       ops.linear_workspace_bytes(m, self.layers[0].self_attn.qkv_proj.weight.shape[0], cfg.hidden_size, "rope_store"),
+                       ops.linear_workspace_bytes(m, 2 * inter, cfg.hidden_size, "silu_mul"), 16)
+            bufs[key] = dict(resid_p=torch.zeros(rows * cfg.hidden_size, dtype=torch.bfloat16, device=device),
+                             act_p=torch.zeros(rows * inter, dtype=torch.bfloat16, device=device),
+                             ws=torch.zeros(need, dtype=torch.uint8, device=device))
+        return bufs[key]
+
     def _forward_decode_fused(self, residual, positions):
         """Decode step with 6 launches per layer (qkv, attention split + combine, o_proj, gate_up, down): the norms ride in the
         projections (folded weights + epilogue row scale), residual adds / SiLU*mul / RoPE+store are GEMM epilogues.
-        `residual` is the running residual stream (the embedding output, updated in place); the final norm belongs to the LM
-        head's launch, so this returns the un-normalised stream and flags compute_logits."""
+        `residual` is the running residual stream (the embedding output, updated in place); every GEMM that updates it also
+        writes it in fragment order for the next GEMM (csrc/linear_stream.hip), and the MLP activation exists only in that
+        order.  The final norm belongs to the LM head's launch, so this returns the un-normalised stream and flags compute_logits."""
         from .. import ops
         from ..utils.context import get_context
         ctx = get_context()
         fw = self._folded_weights()
+        m = residual.shape[0]
+        b = self._decode_buffers(m, residual.device)
+        resid_p, act_p, ws = b["resid_p"], b["act_p"], b["ws"]
         for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
-            q = ops.fused_linear(residual, fw["qkv"][i], bias=a.qkv_proj.bias, norm_folded=True, norm_eps=layer.input_layernorm.eps,
-                                 epilogue="rope_store",
+            x, xrows = (residual, None) if i == 0 else (resid_p, m)       # layer 0 reads the embedding rows as they are
+            q = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
+                                 norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws,
                                  rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
                                            v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
                                            num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
             o = a.attn.decode_attend(q)
-            ops.fused_linear(o, a.o_proj.weight, epilogue="residual_add", out=residual)
-            act = ops.fused_linear(residual, fw["gate_up"][i], norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
-                                   epilogue="silu_mul")
-            ops.fused_linear(act, mlp.down_proj.weight, epilogue="residual_add", out=residual)
-        self._pending_final_norm = True
+            ops.fused_linear(o, a.o_proj.weight, epilogue="residual_add", out=residual, out_packed=resid_p, workspace=ws)
+            ops.fused_linear(resid_p, fw["gate_up"][i], x_packed_rows=m, norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
+                             epilogue="silu_mul", out_packed=act_p, want_out=False, workspace=ws)
+            ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
+                             workspace=ws)
+        self._pending_final_norm = resid_p
         return residual
 
     def compute_logits(self, hidden_states):
         w = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight
-        if getattr(self, "_pending_final_norm", False):              # fused decode path: final RMSNorm in the LM-head prologue
-            self._pending_final_norm = False
+        packed = getattr(self, "_pending_final_norm", None)
+        if packed is not None:                                        # fused decode path: final RMSNorm in the LM-head launch
+            self._pending_final_norm = None
             from .. import ops
-            return ops.fused_linear(hidden_states, self._folded_weights()["head"], norm_folded=True, norm_eps=self.norm.eps)
+            return ops.fused_linear(packed, self._folded_weights()["head"], x_packed_rows=hidden_states.shape[0], norm_folded=True,
+                                    norm_eps=self.norm.eps)
         return linear(hidden_states, w)
 
     @torch.no_grad()

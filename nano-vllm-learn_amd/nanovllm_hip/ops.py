@@ -275,16 +275,51 @@ def linear_small_m(x, weight, bias=None, silu_mul=False):
     return out.view(*x.shape[:-1], out.shape[1])
 
 
-def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_folded=False, epilogue="none", out=None, rope=None):
+def pack_rows(x, rows=None):
+    """[M, C] bf16 -> the MFMA-fragment order the streaming GEMM reads at full address rate (nvh_pack_index):
+    [ceil(M/16)][C/32][lane = 16 * (col/8 % 4) + row % 16][8], rows padded with zeros.  Torch-side helper (tests, first layer)."""
+    m, c = x.shape
+    assert c % 32 == 0
+    mt = (max(m, rows or m) + 15) // 16
+    xp = torch.zeros((mt * 16, c), dtype=x.dtype, device=x.device)
+    xp[:m] = x
+    return xp.view(mt, 16, c // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(-1)
+
+
+def unpack_rows(xp, m, c):
+    """Inverse of pack_rows: flat fragment-order buffer -> [m, c]."""
+    mt = xp.numel() // (16 * c)
+    return xp.view(mt, c // 32, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(mt * 16, c)[:m]
+
+
+def linear_workspace_bytes(m, n, k, epilogue="none") -> int:
+    return int(_lib.load().nvh_linear_small_m_workspace(m, n, k, _EPI_CODES[epilogue]))
+
+
+_EPI_CODES = {"none": _lib.EPI_NONE, "silu_mul": _lib.EPI_SILU_MUL, "residual_add": _lib.EPI_RESIDUAL_ADD, "rope_store": _lib.EPI_ROPE_STORE}
+
+
+def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_folded=False, epilogue="none", out=None, rope=None,
+                 x_packed_rows=None, out_packed=None, workspace=None, want_out=True):
     """nvh_linear_small_m_ex: x [M<=64, K] . weight[N, K]^T with an optional RMSNorm prologue and one of the epilogues
     "none" (+bias) | "silu_mul" | "residual_add" (out = the residual stream, updated in place) | "rope_store"
-    (rope = dict(positions, cos_sin, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads, head_dim); returns q [M, H*D])."""
+    (rope = dict(positions, cos_sin, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads, head_dim); returns q [M, H*D]).
+    Streaming form: x_packed_rows = M when `x` is a flat fragment-order buffer (pack_rows); out_packed = a flat bf16 buffer
+    that receives the result in fragment order as well; workspace = a ZERO-FILLED uint8 buffer of linear_workspace_bytes()
+    (needed for K > 1024); want_out=False skips the row-major output when out_packed is given ("none" / "silu_mul")."""
     _require_gpu_bf16(x=x, weight=weight)
-    m, k = x.shape
-    n = weight.shape[0]
-    assert x.stride(1) == 1 and weight.is_contiguous() and weight.shape[1] == k and m <= LINEAR_SMALL_M_MAX
+    n, k = weight.shape
+    if x_packed_rows is not None:
+        m = int(x_packed_rows)
+        assert x.dim() == 1 and x.numel() >= ((m + 15) // 16) * 16 * k and x.is_contiguous()
+    else:
+        m = x.shape[0]
+        assert x.shape[1] == k and x.stride(1) == 1
+    assert weight.is_contiguous() and m <= LINEAR_SMALL_M_MAX
     d = _lib.LinearDesc()
-    d.x, d.w, d.m, d.n, d.k, d.x_row_stride = x.data_ptr(), weight.data_ptr(), m, n, k, x.stride(0)
+    d.x, d.w, d.m, d.n, d.k = x.data_ptr(), weight.data_ptr(), m, n, k
+    d.x_row_stride = k if x_packed_rows is not None else x.stride(0)
+    d.x_packed = 1 if x_packed_rows is not None else 0
     d.bias = bias.data_ptr() if bias is not None else None
     if norm_folded:                                   # `weight` already carries the norm weight: w * diag(g)
         assert norm_weight is None
@@ -311,9 +346,17 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
         d.h, d.kvh, d.hd = h, kvh, hd
     else:
         raise ValueError(epilogue)
-    if out is None:
+    if out_packed is not None:
+        _require_gpu_bf16(out_packed=out_packed)
+        assert out_packed.is_contiguous() and out_packed.numel() >= ((m + 15) // 16) * 16 * cols
+        d.out_packed = out_packed.data_ptr()
+    if workspace is not None:
+        assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.is_contiguous()
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel()
+    if out is None and (want_out or out_packed is None):
         out = torch.empty((m, cols), dtype=torch.bfloat16, device=x.device)
-    d.out, d.out_row_stride = out.data_ptr(), out.stride(0)
+    if out is not None:
+        d.out, d.out_row_stride = out.data_ptr(), out.stride(0)
     rc = _lib.load().nvh_linear_small_m_ex(ctypes.byref(d), NVH_BF16, _stream())
     _lib.check(rc, "nvh_linear_small_m_ex")
     return out

@@ -118,3 +118,19 @@ def test_context_fields_match_reference():
     assert (c.is_prefill, c.slot_mapping, c.context_lens, c.block_tables) == (False, 1, 2, 3)
     reset_context()
     assert get_context() == Context()
+
+
+def test_pack_index_matches_the_torch_packer():
+    """nvh_pack_index (host-callable) is the layout ops.pack_rows / unpack_rows produce."""
+    import torch
+    from nanovllm_hip import _lib, ops
+    lib = _lib.load()
+    m, c = 37, 96
+    x = torch.arange(m * c, dtype=torch.float32).view(m, c).bfloat16()
+    xp = ops.pack_rows(x)
+    assert xp.numel() == 48 * c
+    for row, col in [(0, 0), (1, 0), (0, 8), (15, 31), (16, 0), (36, 95), (17, 40)]:
+        assert xp[lib.nvh_pack_index(row, col, c)] == x[row, col]
+    assert torch.equal(ops.unpack_rows(xp, m, c), x)
+    assert lib.nvh_linear_small_m_workspace(32, 896, 896, 2) == 0           # K <= 1024: one workgroup per tile, no hand-off
+    assert lib.nvh_linear_small_m_workspace(32, 896, 4864, 2) >= 56 * 4 + 56 * 5 * (2 * 256 + 32) * 4

@@ -254,3 +254,93 @@ def test_fused_linear_folded_norm(m, n, k, epi):
     err = (out - ref).abs()
     assert err.max() <= 0.03 * ref.abs().max()                      # bf16-level agreement of two valid roundings of the same math
     assert (err / (ref.abs() + 0.05 * ref.abs().max())).mean() < 0.01
+
+
+# ---- streaming GEMM (csrc/linear_stream.hip): split-K hand-off, fragment-packed activations, multi-tile workgroups
+
+def _zero_ws(nbytes):
+    return torch.zeros(max(nbytes, 16), dtype=torch.uint8, device="cuda")
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 896, 4864), (3, 3584, 18944), (64, 512, 2048), (17, 64, 1088)])
+def test_stream_linear_split_k_residual_add(m, n, k):
+    """K > 1024 is split over workgroups; the last arriver sums the partials in split order: result within one bf16 rounding
+    of the fp32 reference, bitwise identical across repeats, tickets left at zero."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(n + k)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.02).bfloat16().cuda()
+    res0 = torch.randn(m, n, generator=g).bfloat16().cuda()
+    need = ops.linear_workspace_bytes(m, n, k, "residual_add")
+    assert need > 0
+    ws = _zero_ws(need)
+    ref = torch.nn.functional.linear(x.float(), w.float()) + res0.float()
+    outs = []
+    for _ in range(3):
+        res = res0.clone()
+        ops.fused_linear(x, w, epilogue="residual_add", out=res, workspace=ws)
+        outs.append(res)
+    torch.cuda.synchronize()
+    _close(outs[0], ref)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    tiles = n // 16
+    assert int(ws[: tiles * 4].view(torch.int32).abs().sum()) == 0
+
+
+def test_stream_linear_split_k_silu_and_rope():
+    """The non-linear epilogues run in the last arriver on the complete sums (Qwen2-7B tp=4 shapes: hidden 3584, heads 7/1 x 128)."""
+    from nanovllm_hip import ops
+    from nanovllm_hip.models.qwen import cos_sin_table
+    g = torch.Generator().manual_seed(5)
+    m, k, inter = 32, 3584, 1184
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(2 * inter, k, generator=g) * 0.02).bfloat16().cuda()
+    gu = torch.nn.functional.linear(x.float(), w.float()).bfloat16()
+    ref = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+    ws = _zero_ws(ops.linear_workspace_bytes(m, 2 * inter, k, "silu_mul"))
+    out = ops.fused_linear(x, w, epilogue="silu_mul", workspace=ws)
+    torch.cuda.synchronize()
+    err = (out.float() - ref.float()).abs()
+    assert (err <= 2.0 ** -6 * ref.float().abs() + 2e-3).all(), err.max()
+    # rope_store: the split-K streaming kernel against the loop kernel (no workspace -> fallback), same rounding points
+    H, KVH, D, bs = 7, 1, 128, 256
+    n = (H + 2 * KVH) * D
+    wq = (torch.randn(n, k, generator=g) * 0.02).bfloat16().cuda()
+    b = torch.randn(n, generator=g).bfloat16().cuda()
+    cs = cos_sin_table(D, 4096, 1e6, "cuda")
+    pos = torch.randint(0, 4096, (m,), generator=g).cuda()
+    slots = torch.randperm(4 * bs, generator=g)[:m].int().cuda()
+    caches = [torch.zeros(2, 4, bs, KVH, D, dtype=torch.bfloat16, device="cuda") for _ in range(2)]
+    qs = []
+    for i, wsp in enumerate((None, _zero_ws(ops.linear_workspace_bytes(m, n, k, "rope_store")))):
+        rope = dict(positions=pos, cos_sin=cs, k_cache=caches[i][0], v_cache=caches[i][1], slot_mapping=slots, num_heads=H, num_kv_heads=KVH, head_dim=D)
+        qs.append(ops.fused_linear(x, wq, bias=b, epilogue="rope_store", rope=rope, workspace=wsp))
+    torch.cuda.synchronize()
+    _close(qs[1], qs[0].float(), rel=2.0 ** -7, abs_=2e-3)
+    _close(caches[1], caches[0].float(), rel=2.0 ** -7, abs_=2e-3)
+
+
+@pytest.mark.parametrize("m,n,k,epi", [(32, 9728, 896, "silu_mul"), (32, 896, 4864, "residual_add"), (20, 1152, 896, "none"), (32, 151936, 896, "none")])
+def test_stream_linear_packed_activations(m, n, k, epi):
+    """Fragment-packed x gives bit-identical results to row-major x (same arithmetic, different fetch), and out_packed is the
+    row-major output in fragment order."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(n * 7 + k)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.03).bfloat16().cuda()
+    folded = epi != "residual_add"
+    cols = n // 2 if epi == "silu_mul" else n
+    ws = _zero_ws(ops.linear_workspace_bytes(m, n, k, epi))
+    res0 = torch.randn(m, n, generator=g).bfloat16().cuda() if epi == "residual_add" else None
+    kw = dict(norm_folded=folded, norm_eps=1e-6, epilogue=epi, workspace=ws)
+    out_a = ops.fused_linear(x, w, out=res0.clone() if res0 is not None else None, **kw)
+    packed = torch.zeros(((m + 15) // 16) * 16 * cols, dtype=torch.bfloat16, device="cuda")
+    out_b = ops.fused_linear(ops.pack_rows(x), w, x_packed_rows=m, out=res0.clone() if res0 is not None else None, out_packed=packed, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(out_a, out_b)
+    assert torch.equal(ops.unpack_rows(packed, m, cols), out_b)
+    if epi in ("none", "silu_mul"):                       # packed-only output
+        packed2 = torch.zeros_like(packed)
+        assert ops.fused_linear(ops.pack_rows(x), w, x_packed_rows=m, out_packed=packed2, want_out=False, **kw) is None
+        torch.cuda.synchronize()
+        assert torch.equal(packed2, packed)

@@ -19,34 +19,44 @@ torch.manual_seed(0)
 x = torch.randn(M, HID, device=dev, dtype=torch.bfloat16)
 act = torch.randn(M, INTER, device=dev, dtype=torch.bfloat16)
 res = torch.randn(M, HID, device=dev, dtype=torch.bfloat16)
-L = 6                                         # rotate weights so every call streams from HBM, not L2/MALL of its own previous call
-w_gu = [torch.randn(2 * INTER, HID, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(L)]
-w_dn = [torch.randn(HID, INTER, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(L)]
-w_o = [torch.randn(HID, H * D, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(L)]
+# rotate over > 256 MB of weights per shape so every call streams from HBM (the Infinity Cache holds 256 MB);
+# "warm" = the same weights every call (what a prefetch of the next GEMM's weights would give)
+def copies(n, k):
+    cnt = int(320e6 / (n * k * 2)) + 1
+    return [torch.randn(n, k, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(cnt)]
+w_gu, w_dn, w_o = copies(2 * INTER, HID), copies(HID, INTER), copies(HID, H * D)
 stamps = torch.zeros(1024 * 64, dtype=torch.int64, device=dev)
 lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
-names = ["entry", "kernargs arrived", "x loads issued", "W DMA issued", "first group landed", "K loop done", "after barrier", "end"]
-order = [0, 6, 7, 1, 2, 3, 4, 5]
+names = ["entry", "W DMA issued", "x loads issued", "all landed", "MFMAs done", "reduced / last arriver summed", "end"]
+ws = torch.zeros(4 << 20, dtype=torch.uint8, device=dev)
 
-def report(tag, nwg, waves):
+def report(tag, nwg, waves=4):
     torch.cuda.synchronize()
-    st = stamps.cpu().numpy()[: nwg * 64].reshape(nwg, 8, 8)[:, :waves, :][:, :, order].astype(np.float64) * 0.01
+    st = stamps.cpu().numpy()[: nwg * 64].reshape(nwg, 8, 8)[:, :waves, :7].astype(np.float64) * 0.01
+    live = st[..., 6] > 0                                    # workgroups that were not the last arriver stop after stamp 4
     t0 = st[..., 0].min()
-    print(f"{tag}: {nwg} workgroups x {waves} waves; span (first entry -> last end) {st[..., 7].max() - t0:.2f} us")
+    print(f"{tag}: {nwg} workgroups x {waves} waves; span (first entry -> last end) {st[..., 6].max() - t0:.2f} us")
     for k, n in enumerate(names):
-        v = st[..., k] - t0
-        d = "" if k == 0 else f"   delta: med {np.median(st[..., k] - st[..., k - 1]):5.2f} p90 {np.percentile(st[..., k] - st[..., k - 1], 90):5.2f} max {(st[..., k] - st[..., k - 1]).max():5.2f}"
-        print(f"   {k} {n:<20} min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}{d}")
+        sel = live if k >= 5 else np.ones_like(live)
+        v = (st[..., k] - t0)[sel]
+        d = ""
+        if k:
+            dd = (st[..., k] - st[..., k - 1])[sel]
+            d = f"   delta: med {np.median(dd):5.2f} p90 {np.percentile(dd, 90):5.2f} max {dd.max():5.2f}"
+        print(f"   {k} {n:<30} min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}{d}")
 
-for rep in range(3):
-    for l in range(L):
-        ops.fused_linear(x, w_gu[l], norm_folded=True, norm_eps=1e-6, epilogue="silu_mul")
-report("gate_up  K=896 N=9728 silu (folded norm)", INTER // 16, 4)
-for rep in range(3):
-    for l in range(L):
-        ops.fused_linear(act, w_dn[l], epilogue="residual_add", out=res)
-report("down     K=4864 N=896 residual", HID // 16, 8)
-for rep in range(3):
-    for l in range(L):
-        ops.fused_linear(x, w_o[l], epilogue="residual_add", out=res)
-report("o_proj   K=896 N=896 residual", HID // 16, 4)
+def run(tag, nwg, fn, ws_list):
+    for warm in (False, True):
+        stamps.zero_()
+        for l in range(2 * len(ws_list)):
+            fn(ws_list[0 if warm else l % len(ws_list)])
+        report(tag + (" [warm: same weights every call]" if warm else " [cold: weights from HBM]"), nwg)
+
+xp = ops.pack_rows(x)
+actp = ops.pack_rows(act)
+run("gate_up  K=896 N=9728 silu folded-norm, row-major x", INTER // 16, lambda w: ops.fused_linear(x, w, norm_folded=True, norm_eps=1e-6, epilogue="silu_mul"), w_gu)
+run("gate_up  same, packed x", INTER // 16, lambda w: ops.fused_linear(xp, w, x_packed_rows=M, norm_folded=True, norm_eps=1e-6, epilogue="silu_mul"), w_gu)
+run("down     K=4864 N=896 residual, split-K 5, row-major x", 5 * HID // 16, lambda w: ops.fused_linear(act, w, epilogue="residual_add", out=res, workspace=ws), w_dn)
+run("down     same, packed x", 5 * HID // 16, lambda w: ops.fused_linear(actp, w, x_packed_rows=M, epilogue="residual_add", out=res, workspace=ws), w_dn)
+run("o_proj   K=896 N=896 residual, row-major x", HID // 16, lambda w: ops.fused_linear(x, w, epilogue="residual_add", out=res), w_o)
+run("o_proj   same, packed x", HID // 16, lambda w: ops.fused_linear(xp, w, x_packed_rows=M, epilogue="residual_add", out=res), w_o)
