@@ -65,8 +65,11 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
                       int64_t k_row_stride, int64_t v_row_stride, int dtype, void* stream);
 
 /*
- * Bytes of caller-owned scratch nvh_paged_decode needs (split-KV partials); a pure function of the
- * static shapes so it can be allocated once before graph capture.
+ * Bytes of caller-owned scratch nvh_paged_decode needs; a pure function of the static shapes so it can be
+ * allocated once before graph capture.  Layout: a fixed 64 KiB header of arrival tickets (one uint32 per
+ * (sequence, kv head)), then the partial records of the context chunks.  The caller ZERO-FILLS the buffer once
+ * (hipMemset / torch.zeros); every launch returns its tickets to zero, so the buffer is reusable across calls,
+ * shapes and graph replays without further clearing.
  */
 size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int block_size);
 
@@ -89,6 +92,17 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
                      int batch, int h, int kvh, int hd, int block_size, int max_blocks,
                      int64_t q_row_stride, int64_t bt_row_stride, float scale,
                      int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * nvh_paged_decode that ALSO writes the bf16 result in MFMA-fragment order (out_packed: [ceil(batch/16)][h*hd/32][64][8],
+ * nvh_pack_index(row = sequence, col = head*hd + dim, cols = h*hd)) for a following nvh_linear_small_m_ex with x_packed = 1
+ * (the output projection, models/qwen3.py:118).  Same arguments otherwise; `out` is still written.
+ */
+int nvh_paged_decode_packed(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
+                            const int32_t* block_tables, const int32_t* context_lens,
+                            int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                            int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                            int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Fused decode step for one layer: store this step's K/V row of every sequence, then attend.

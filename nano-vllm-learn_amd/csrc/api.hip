@@ -83,6 +83,8 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
                                 k_row_stride, v_row_stride, (hipStream_t)stream);
 }
 
+static constexpr size_t kDecodeTicketBytes = 65536;       // 16384 tickets
+
 static int decode_num_splits(int hd, int max_blocks, int block_size) {
     const int split = decode_split_tokens(hd);
     const int64_t cap = (int64_t)max_blocks * block_size;
@@ -93,15 +95,18 @@ static int decode_num_splits(int hd, int max_blocks, int block_size) {
 size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int block_size) {
     if (batch <= 0 || h <= 0 || (hd != 64 && hd != 128) || max_blocks <= 0 || block_size <= 0) return 0;
     const size_t parts = (size_t)batch * h * decode_num_splits(hd, max_blocks, block_size);
-    return parts * (size_t)(hd + 2) * sizeof(float);
+    // a fixed header of arrival tickets (one per (sequence, kv head); the SAME bytes whatever the shape, so that one
+    // workspace serves calls of different shapes), then the partial records
+    return kDecodeTicketBytes + parts * (size_t)(hd + 2) * sizeof(float);
 }
 
-int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
-                     const int32_t* block_tables, const int32_t* context_lens,
-                     int batch, int h, int kvh, int hd, int block_size, int max_blocks,
-                     int64_t q_row_stride, int64_t bt_row_stride, float scale,
-                     int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+static int paged_decode_impl(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
+                             const int32_t* block_tables, const int32_t* context_lens,
+                             int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                             int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
     if (batch == 0) return 0;
+    if (out_packed && (!aligned16(out_packed) || ((int64_t)h * hd) % 32)) { set_error("paged_decode: out_packed needs 16-byte alignment and h*hd %% 32 == 0"); return NVH_E_ALIGN; }
     if (dtype != NVH_BF16 || (out_dtype != NVH_BF16 && out_dtype != NVH_F32)) {
         set_error("paged_decode: dtype %d / out_dtype %d unsupported", dtype, out_dtype);
         return NVH_E_DTYPE;
@@ -140,13 +145,36 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
     a.batch = batch; a.h = h; a.kvh = kvh; a.hd = hd;
     a.block_size = block_size; a.max_blocks = max_blocks;
     a.num_splits = decode_num_splits(hd, max_blocks, block_size);
-    a.ws_acc = (float*)workspace;
+    if ((size_t)batch * kvh * 4 > kDecodeTicketBytes) { set_error("paged_decode: batch * kvh = %d > %zu tickets", batch * kvh, kDecodeTicketBytes / 4); return NVH_E_SHAPE; }
+    a.counters = reinterpret_cast<unsigned*>(workspace);
+    a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeTicketBytes);
     a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;
+    a.chunks = decode_chunks(batch, kvh, a.num_splits);
+    a.out_packed = (uint16_t*)out_packed;
     a.q_row_stride = q_row_stride; a.bt_row_stride = bt_row_stride;
     a.scale_log2 = scale * kLog2e;
     a.out_f32 = out_dtype == NVH_F32;
     a.stamps = g_stamps;
     return launch_paged_decode(a, (hipStream_t)stream);
+}
+
+int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* v_cache,
+                     const int32_t* block_tables, const int32_t* context_lens,
+                     int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                     int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                     int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return paged_decode_impl(out, nullptr, q, k_cache, v_cache, block_tables, context_lens, batch, h, kvh, hd, block_size, max_blocks,
+                             q_row_stride, bt_row_stride, scale, dtype, out_dtype, workspace, workspace_bytes, stream);
+}
+
+int nvh_paged_decode_packed(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
+                            const int32_t* block_tables, const int32_t* context_lens,
+                            int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                            int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                            int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!out_packed) { set_error("paged_decode_packed: out_packed is NULL"); return NVH_E_NULL; }
+    return paged_decode_impl(out, out_packed, q, k_cache, v_cache, block_tables, context_lens, batch, h, kvh, hd, block_size, max_blocks,
+                             q_row_stride, bt_row_stride, scale, dtype, out_dtype, workspace, workspace_bytes, stream);
 }
 
 int nvh_decode_step(void* out, const void* q, const void* k_new, const void* v_new,

@@ -24,11 +24,16 @@ struct DecodeArgs {
     float scale_log2;            // softmax scale * log2(e)
     int out_f32;
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
+    // chunked kernel (default): partial records [B*KVH][chunks][G*(D+2)] fp32 alias ws_acc; arrival tickets per (b, kv head)
+    unsigned* counters;          // [B*KVH], zero before the launch, left zero by it
+    int chunks;                  // workgroups per (sequence, kv head); passes are dealt to them round-robin
+    uint16_t* out_packed;        // nullable: bf16 output also in MFMA-fragment order [ceil(B/16)][H*D/32][64][8] (pack_index)
 };
 
 // tokens one workgroup of the split kernel covers (static function of head_dim)
 int decode_split_tokens(int hd);
 int launch_paged_decode(const DecodeArgs& a, hipStream_t stream);
+int decode_chunks(int batch, int kvh, int num_splits);
 
 struct RopeStoreArgs {
     uint16_t* qkv;               // [N, (H+2KVH)*D] fused projection output, rotated in place

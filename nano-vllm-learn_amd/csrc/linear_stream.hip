@@ -431,7 +431,8 @@ int launch_linear_stream(const LinearArgs& a_in, hipStream_t stream) {
     a.ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);
     if (a.ksplit > 1) {
         const size_t counters_bytes = (((size_t)a.tiles * 4 + 255) / 256) * 256;
-        if (!a.ws_raw || a.ws_bytes < linear_stream_workspace_bytes(a.M, a.N, a.K, a.epi)) return -100;
+        const int nb = (a.epi == EPI_SILU || a.epi == EPI_ROPE) ? 2 : 1, mt = (a.M + 15) / 16;
+        if (!a.ws_raw || a.ws_bytes < counters_bytes + (size_t)a.tiles * a.ksplit * (nb * mt * 256 + mt * 16) * 4) return -100;
         a.counters = reinterpret_cast<unsigned*>(a.ws_raw);
         a.ws = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(a.ws_raw) + counters_bytes);
     }

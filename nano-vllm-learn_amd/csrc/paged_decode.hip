@@ -274,6 +274,31 @@ __device__ __forceinline__ int chunk_swizzle(int T) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// ds_read_b64_tr_b16 through inline asm: with the builtin hipcc waits vmcnt(0) before the read (it cannot prove the read does
+// not alias the LDS-DMA of the NEXT pass still in flight).  The caller batches these, then `s_waitcnt lgkmcnt(0)` + a
+// scheduling fence before the first use.
+__device__ __forceinline__ u32x2 ds_read_tr16_b64_asm(uint32_t lds_addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ uint32_t lds_offset(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// wave-uniform int32 load through the constant address space: stays a scalar load (lgkmcnt) inside loops that also hold
+// stores and LDS-DMA, where a plain load would be a vector load whose vmcnt wait drains the DMA queue
+__device__ __forceinline__ int32_t load_uniform_i32(const int32_t* p) {
+    return *(const __attribute__((address_space(4))) int32_t*)(uintptr_t)p;
+}
+
+// write-through store / cache-bypassing load of one float (global_store_dword / global_load_dword with sc1)
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_sc1(const float* p) {
+    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 template <int D>
 __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const DecodeArgs a, const int G) {
     using geo = MGeo<D>;
@@ -453,6 +478,318 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
     NVH_STAMP(7);
 }
 
+// =====================================================================================================
+// Chunked MFMA kernel (default): the split kernel above restructured so that one launch does the whole call.
+//   * grid (KVH*B, chunks): a workgroup walks PASSES of SPLIT tokens (pass p belongs to chunk p % chunks, so the live
+//     passes of a sequence are dealt evenly whatever its length); the host picks chunks ~ 256 / (B*KVH): the launch is
+//     one wave of workgroups over the 256 CUs and the per-launch fixed costs (arguments, dispatch ramp, first-byte
+//     latency, merge, epilogue) are paid once per 2-8 passes instead of once per pass.
+//   * each wave owns two K + V image pairs (double buffer) and runs the online softmax over its passes without any
+//     workgroup barrier: pass p+1's LDS-DMA is issued before pass p is consumed, behind counted vmcnt waits.
+//   * the waves merge through LDS once; with more than one live chunk the workgroup publishes its (max, sum, O) record
+//     write-through (sc1 stores, vmcnt(0), barrier, ticket by a relaxed agent atomic) and the LAST ARRIVER of the
+//     (sequence, kv head) merges all records (sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
+//     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
+//     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
+template <int D>
+__global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const DecodeArgs a, const int G) {
+    using geo = MGeo<D>;
+    constexpr int LPT = geo::LPT, TPI = geo::TPI, WT = geo::WT, NI = geo::NI, ROWB = geo::ROWB, NT = geo::NT;
+    constexpr int NHALF = geo::NHALF, STEPS = geo::STEPS, DT = geo::DT, QI = geo::QI, IMG = geo::IMG;
+    constexpr int WAVES = MW, SPLIT = geo::SPLIT;
+    constexpr int WAVE_LDS = 2 * geo::WAVE_BYTES;             // two (K, V) image pairs per wave
+    static_assert(16 * D * 4 <= IMG, "merge tile must fit in one K image");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[MW * WAVE_LDS + QI * 1024 + MW * 2 * 16 * 4 + 16];
+    unsigned char* const lds_q = lds + MW * WAVE_LDS;
+    float* const lds_ml = reinterpret_cast<float*>(lds_q + QI * 1024);              // [wave][max | sum][16 heads]
+    unsigned* const lds_ticket = reinterpret_cast<unsigned*>(lds_q + QI * 1024 + MW * 2 * 16 * 4);
+
+    const int split = blockIdx.y, kh = blockIdx.x % a.kvh, b = blockIdx.x / a.kvh;   // `split` = chunk index
+    const int NC = a.chunks;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    NVH_STAMP(0);
+    const int ctx = a.context_lens[b];
+    const int live_passes = (ctx + SPLIT - 1) / SPLIT;
+    if (split >= live_passes) {
+        if (split == 0) {                                     // ctx == 0 (padding row): zeros, as the oracle
+            for (int idx = tid; idx < G * D; idx += WAVES * 64) {
+                const int64_t o = ((int64_t)b * a.h + kh * G) * D + idx;
+                if (a.out_f32) reinterpret_cast<float*>(a.out)[o] = 0.f;
+                else reinterpret_cast<uint16_t*>(a.out)[o] = 0;
+                if (a.out_packed) a.out_packed[pack_index(b, kh * G * D + idx, a.h * D)] = 0;
+            }
+        }
+        return;                                               // whole workgroup, before any barrier
+    }
+    const int64_t bt_row = (int64_t)b * a.bt_row_stride;
+    // this wave's tile in pass p starts at token p*SPLIT + wave*WT; block ids are fetched one pass ahead
+    const int wtok = wave * WT;
+    int pass = split;
+    int tok0 = pass * SPLIT + wtok;
+    int bid = load_uniform_i32(a.block_tables + bt_row + min(tok0 / a.block_size, a.max_blocks - 1));
+    int bid_next = load_uniform_i32(a.block_tables + bt_row + min((tok0 + NC * SPLIT) / a.block_size, a.max_blocks - 1));
+    NVH_STAMP(1);
+
+    unsigned char* const lds_w = lds + wave * WAVE_LDS;
+    const int lq = lane & 15;                                 // head column of the MFMA tiles
+    const int lg = lane >> 4;                                 // lane group: k-block of operands / row block of C
+    const int dp = lane % LPT, dr = lane / LPT;               // DMA: chunk position / row inside one instruction
+    const int64_t row = (int64_t)a.kvh * D;                   // elements per token (all kv heads)
+
+    auto issue_kv = [&](int t0, int block_id, int buf) {      // K then V image of the tile starting at token t0
+        const int off0 = t0 - (t0 / a.block_size) * a.block_size;
+        const int64_t base = ((int64_t)block_id * a.block_size + off0) * row + (int64_t)kh * D;
+        const int last = ctx - t0 - 1;                        // rows past the live range repeat the last live row
+        unsigned char* const kimg = lds_w + buf * geo::WAVE_BYTES;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int T = i * TPI + dr;
+            const int Tc = T < last ? T : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.k_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
+                                             (__attribute__((address_space(3))) void*)(kimg + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int T = i * TPI + dr;
+            const int Tc = T < last ? T : last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
+                                             (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, 0);
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
+        {
+            const uint16_t* qp = a.q + (int64_t)b * a.q_row_stride + (int64_t)(kh * G) * D;
+#pragma unroll
+            for (int i = 0; i < QI; ++i) {                    // q: 16 rows, rows >= G repeat the last head
+                const int R = i * TPI + dr;
+                const int g = R < G ? R : G - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qp + g * D + (dp ^ chunk_swizzle<LPT>(R)) * 8),
+                                                 (__attribute__((address_space(3))) void*)(lds_q + i * 1024), 16, 0, 0);
+            }
+        }
+        issue_kv(tok0, bid, 0);
+        NVH_STAMP(2);
+        bf16x8 qf[STEPS];
+        for (int buf = 0;; buf ^= 1) {
+            const int tok_next = tok0 + NC * SPLIT;
+            const bool has_next = tok_next < ctx;             // wave-uniform
+            int bid_nn = 0;
+            if (has_next) {
+                issue_kv(tok_next, bid_next, buf ^ 1);
+                bid_nn = load_uniform_i32(a.block_tables + bt_row + min((tok_next + NC * SPLIT) / a.block_size, a.max_blocks - 1));
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");      // q and this pass's K landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            }
+            const unsigned char* const lds_k = lds_w + buf * geo::WAVE_BYTES;
+            const unsigned char* const lds_v = lds_k + IMG;
+            const int n_live = ctx - tok0;
+            if (pass == split) {
+                NVH_STAMP(3);
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st)
+                    qf[st] = *reinterpret_cast<const bf16x8*>(lds_q + lq * ROWB + (((4 * st + lg) ^ chunk_swizzle<LPT>(lq)) * 16));
+            }
+            // ---- S^T = K Q^T
+            f32x4 sT[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int R = 16 * tt + lq;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(lds_k + R * ROWB + (((4 * st + lg) ^ chunk_swizzle<LPT>(R)) * 16));
+                    sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
+                }
+            }
+            // ---- online softmax (log2 domain): tile max per head, rescale of the running sums
+            float mx = -INFINITY;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool live = 16 * tt + 4 * lg + r < n_live;
+                    sT[tt][r] = live ? sT[tt][r] * a.scale_log2 : -INFINITY;
+                    mx = fmaxf(mx, sT[tt][r]);
+                }
+            mx = max_xor16(mx);
+            mx = max_xor32(mx);                                // finite: token 0 of the tile is live
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = fast_exp2(m_run - m_new);     // first pass: exp2(-inf) = 0
+            m_run = m_new;
+            float lsum = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sT[tt][r] = fast_exp2(sT[tt][r] - m_new);
+                    lsum += sT[tt][r];
+                }
+            l_run = fmaf(l_run, alpha, lsum);                 // per-lane partial sums; alpha is uniform over a head's lanes
+#pragma unroll
+            for (int t = 0; t < DT; ++t) o[t] = o[t] * alpha;
+            if (pass == split) NVH_STAMP(4);
+            if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");   // this pass's V landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (pass == split) NVH_STAMP(5);
+            // ---- O^T += V^T P^T, P as hi + lo bf16
+            const int vq = lq >> 2, vp = lq & 3;              // lane 4q+p of its group addresses key row q, dims 4p..4p+3
+#pragma unroll
+            for (int hh = 0; hh < NHALF; ++hh) {
+                bf16x8 p_hi, p_lo;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float pv = sT[2 * hh + (i >> 2)][i & 3];
+                    p_hi[i] = (__bf16)pv;
+                    p_lo[i] = (__bf16)(pv - (float)p_hi[i]);
+                }
+                const int R = 32 * hh + 4 * lg + vq;          // chunk_swizzle(R) == chunk_swizzle(R + 16)
+                const uint32_t vrow = lds_offset(lds_v + R * ROWB + (vp & 1) * 8);
+                const int swz = chunk_swizzle<LPT>(R);
+                u32x2 vlo[DT], vhi[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const uint32_t off = ((2 * t + (vp >> 1)) ^ swz) * 16;
+                    vlo[t] = ds_read_tr16_b64_asm(vrow + off);
+                    vhi[t] = ds_read_tr16_b64_asm(vrow + 16 * ROWB + off);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    const u32x4 raw = {vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&raw);
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi, o[t], 0, 0, 0);
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo, o[t], 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // image reads done: the buffer may be refilled
+            if (!has_next) break;
+            pass += NC;
+            tok0 = tok_next;
+            bid_next = bid_nn;
+        }
+        l_run = sum_xor16(l_run);
+        l_run = sum_xor32(l_run);
+        NVH_STAMP(6);
+        // ---- this wave's (max, sum, O) into LDS: O^T[dim 16t+4lg+r][head lq] -> fin[head][dim], aliasing its first K image
+        if (lq < G) {
+            float* const fin = reinterpret_cast<float*>(lds_w) + lq * D + 4 * lg;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) *reinterpret_cast<f32x4*>(fin + 16 * t) = o[t];
+            if (lg == 0) {
+                lds_ml[(wave * 2 + 0) * 16 + lq] = m_run;
+                lds_ml[(wave * 2 + 1) * 16 + lq] = l_run;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- merge the live waves (those with a live tile in the workgroup's first pass), then the live chunks
+    const int n_waves = min(WAVES, (ctx - split * SPLIT + WT - 1) / WT);
+    const int live_chunks = min(NC, live_passes);
+    constexpr int EPT = 16 * D / (MW * 64);                   // elements per thread when G == 16
+    float Mv[EPT], Lv[EPT], Ov[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = tid + e * WAVES * 64;
+        Mv[e] = -INFINITY; Lv[e] = 0.f; Ov[e] = 0.f;
+        if (idx < G * D) {
+            const int g = idx / D;
+            float M = -INFINITY;
+            for (int w = 0; w < n_waves; ++w) M = fmaxf(M, lds_ml[(w * 2 + 0) * 16 + g]);
+            float ov = 0.f, L = 0.f;
+            for (int w = 0; w < n_waves; ++w) {
+                const float f = fast_exp2(lds_ml[(w * 2 + 0) * 16 + g] - M);
+                ov = fmaf(reinterpret_cast<const float*>(lds + w * WAVE_LDS)[idx], f, ov);
+                L = fmaf(lds_ml[(w * 2 + 1) * 16 + g], f, L);
+            }
+            Mv[e] = M; Lv[e] = L; Ov[e] = ov;
+        }
+    }
+    if (live_chunks > 1) {
+        const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
+        float* const recs = a.ws_acc + ((int64_t)b * a.kvh + kh) * NC * rec;
+        float* const mine = recs + (int64_t)split * rec;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + e * WAVES * 64;
+            if (idx < G * D) {
+                st_sc1(mine + idx, Ov[e]);
+                if (idx % D == 0) {
+                    st_sc1(mine + G * D + idx / D, Mv[e]);
+                    st_sc1(mine + G * D + G + idx / D, Lv[e]);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* const ctr = a.counters + (int64_t)b * a.kvh + kh;
+            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *lds_ticket = old;
+        }
+        __syncthreads();
+        if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + e * WAVES * 64;
+            if (idx < G * D) {
+                const int g = idx / D;
+                float M = -INFINITY, ov = 0.f, L = 0.f;
+                for (int c0 = 0; c0 < live_chunks; c0 += 8) {
+                    float mv[8], lv[8], av[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
+                        const float* r = recs + (int64_t)c * rec;
+                        mv[i] = ld_sc1(r + G * D + g);
+                        lv[i] = ld_sc1(r + G * D + G + g);
+                        av[i] = ld_sc1(r + idx);
+                    }
+                    float Mc = M;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c0 + i < live_chunks) Mc = fmaxf(Mc, mv[i]);
+                    const float fo = fast_exp2(M - Mc);        // M = -inf on the first group -> 0
+                    ov *= fo;
+                    L *= fo;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        if (c0 + i < live_chunks) {
+                            const float f = fast_exp2(mv[i] - Mc);
+                            ov = fmaf(av[i], f, ov);
+                            L = fmaf(lv[i], f, L);
+                        }
+                    M = Mc;
+                }
+                Lv[e] = L; Ov[e] = ov;
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int idx = tid + e * WAVES * 64;
+        if (idx < G * D) {
+            const float r = Ov[e] / Lv[e];
+            const int64_t oidx = ((int64_t)b * a.h + kh * G) * D + idx;
+            if (a.out_f32) reinterpret_cast<float*>(a.out)[oidx] = r;
+            else reinterpret_cast<__bf16*>(a.out)[oidx] = (__bf16)r;
+            if (a.out_packed) a.out_packed[pack_index(b, kh * G * D + idx, a.h * D)] = __builtin_bit_cast(uint16_t, (__bf16)r);
+        }
+    }
+    NVH_STAMP(7);
+}
+
 // One thread per output element (b, h, d): all live partials are requested before any is used.
 template <int D>
 __global__ __launch_bounds__(256) void paged_decode_combine_kernel(const DecodeArgs a) {
@@ -528,6 +865,13 @@ int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
 }
 
 template <int D>
+int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
+    dim3 grid(a.kvh * a.batch, a.chunks);
+    hipLaunchKernelGGL((paged_decode_chunked_kernel<D>), grid, dim3(MW * 64), 0, stream, a, g);
+    return check_launch("paged_decode_chunked");
+}
+
+template <int D>
 int launch_mfma(const DecodeArgs& a, int g, hipStream_t stream) {
     dim3 grid(a.kvh * a.batch, a.num_splits);
     hipLaunchKernelGGL((paged_decode_split_mfma_kernel<D>), grid, dim3(MW * 64), 0, stream, a, g);
@@ -542,20 +886,32 @@ static_assert(MGeo<64>::SPLIT == Geo<64>::SPLIT && MGeo<128>::SPLIT == Geo<128>:
 
 int decode_max_group(void) { return 16; }
 
-// NVH_DECODE_IMPL=valu selects the VALU split kernel (groups <= 8) for A/B measurements; default is MFMA.
-static bool use_valu() {
-    static const bool v = [] {
+// NVH_DECODE_IMPL selects an older formulation for A/B measurements: "valu" = VALU split kernel (groups <= 8) + combine,
+// "split" = single-pass MFMA split kernel + combine; default = the chunked MFMA kernel (one launch).
+static int decode_impl() {
+    static const int v = [] {
         const char* e = getenv("NVH_DECODE_IMPL");
-        return e && e[0] == 'v';
+        return !e ? 0 : e[0] == 'v' ? 1 : e[0] == 's' ? 2 : 0;
     }();
     return v;
+}
+
+// workgroups per (sequence, kv head): one wave of workgroups over the chip, at most one per pass
+int decode_chunks(int batch, int kvh, int num_splits) {
+    static const int forced = [] { const char* e = getenv("NVH_DECODE_CHUNKS"); return e ? atoi(e) : 0; }();   // A/B knob
+    int c = forced > 0 ? forced : (256 + batch * kvh / 2) / (batch * kvh);
+    if (c < 1) c = 1;
+    return c > num_splits ? num_splits : c;
 }
 
 int launch_paged_decode(const DecodeArgs& a, hipStream_t stream) {
     if (a.batch == 0) return 0;
     const int g = a.h / a.kvh;
-    if (use_valu() && g <= 8) return a.hd == 64 ? launch_valu_d<64>(a, g, stream) : launch_valu_d<128>(a, g, stream);
-    return a.hd == 64 ? launch_mfma<64>(a, g, stream) : launch_mfma<128>(a, g, stream);
+    const int impl = decode_impl();
+    if (impl != 0 && a.out_packed) { set_error("paged_decode: out_packed needs the chunked kernel (unset NVH_DECODE_IMPL)"); return -2; }
+    if (impl == 1 && g <= 8) return a.hd == 64 ? launch_valu_d<64>(a, g, stream) : launch_valu_d<128>(a, g, stream);
+    if (impl == 2) return a.hd == 64 ? launch_mfma<64>(a, g, stream) : launch_mfma<128>(a, g, stream);
+    return a.hd == 64 ? launch_chunked<64>(a, g, stream) : launch_chunked<128>(a, g, stream);
 }
 
 }  // namespace nvh

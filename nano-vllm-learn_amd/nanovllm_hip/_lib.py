@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  (imported first on purpose: libnvh_attn.so binds to the HIP runtime torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnvh_attn.so")
+LIB_PATH = os.environ.get("NVH_LIB_PATH") or os.path.join(_HERE, "lib", "libnvh_attn.so")   # override: A/B of two builds
 
 NVH_BF16 = 0
 NVH_F32 = 1
@@ -38,6 +38,9 @@ _SIGS = {
     "nvh_paged_decode": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_i32p, _c_i32p] + [ctypes.c_int] * 6 +
                          [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "nvh_paged_decode_packed": (ctypes.c_int, [ctypes.c_void_p] * 5 + [_c_i32p, _c_i32p] + [ctypes.c_int] * 6 +
+                                [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nvh_decode_step": (ctypes.c_int, [ctypes.c_void_p] * 6 + [_c_i32p] * 3 + [ctypes.c_int] * 6 +
                         [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),

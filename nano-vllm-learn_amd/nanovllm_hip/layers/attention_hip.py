@@ -37,12 +37,13 @@ class Attention(nn.Module):
         q, k, v = qkv.split([h * d, kvh * d, kvh * d], dim=-1)
         return self._attend(q.view(-1, h, d), k.view(-1, kvh, d), v.view(-1, kvh, d), context, store=False)
 
-    def decode_attend(self, q):
-        """Decode attention for rows whose K/V are ALREADY in the cache (stored by the fused qkv launch): no store here."""
+    def decode_attend(self, q, out_packed=None):
+        """Decode attention for rows whose K/V are ALREADY in the cache (stored by the fused qkv launch): no store here.
+        out_packed: optional flat buffer that also receives the output in fragment order for the output projection."""
         context = get_context()
         o = ops.flash_attn_with_kvcache(q.view(-1, 1, self.num_heads, self.head_dim), self.k_cache, self.v_cache,
                                         cache_seqlens=context.context_lens, block_table=context.block_tables,
-                                        softmax_scale=self.scale, causal=True)
+                                        softmax_scale=self.scale, causal=True, out_packed=out_packed)
         return o.view(-1, self.num_heads * self.head_dim)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):

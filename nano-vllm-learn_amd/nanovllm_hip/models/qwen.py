@@ -305,6 +305,7 @@ class QwenForCausalLM(nn.Module):
                        ops.linear_workspace_bytes(m, 2 * inter, cfg.hidden_size, "silu_mul"), 16)
             bufs[key] = dict(resid_p=torch.zeros(rows * cfg.hidden_size, dtype=torch.bfloat16, device=device),
                              act_p=torch.zeros(rows * inter, dtype=torch.bfloat16, device=device),
+                             attn_p=torch.zeros(rows * self.layers[0].self_attn.o_proj.weight.shape[1], dtype=torch.bfloat16, device=device),
                              ws=torch.zeros(need, dtype=torch.uint8, device=device))
         return bufs[key]
 
@@ -320,7 +321,7 @@ class QwenForCausalLM(nn.Module):
         fw = self._folded_weights()
         m = residual.shape[0]
         b = self._decode_buffers(m, residual.device)
-        resid_p, act_p, ws = b["resid_p"], b["act_p"], b["ws"]
+        resid_p, act_p, attn_p, ws = b["resid_p"], b["act_p"], b["attn_p"], b["ws"]
         for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
             x, xrows = (residual, None) if i == 0 else (resid_p, m)       # layer 0 reads the embedding rows as they are
@@ -329,8 +330,9 @@ class QwenForCausalLM(nn.Module):
                                  rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
                                            v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
                                            num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
-            o = a.attn.decode_attend(q)
-            ops.fused_linear(o, a.o_proj.weight, epilogue="residual_add", out=residual, out_packed=resid_p, workspace=ws)
+            a.attn.decode_attend(q, out_packed=attn_p)
+            ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
+                             workspace=ws)
             ops.fused_linear(resid_p, fw["gate_up"][i], x_packed_rows=m, norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
                              epilogue="silu_mul", out_packed=act_p, want_out=False, workspace=ws)
             ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,

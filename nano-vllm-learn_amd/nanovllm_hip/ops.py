@@ -73,15 +73,16 @@ def decode_workspace_bytes(batch, num_heads, head_dim, max_blocks, block_size) -
 
 
 def reserve_workspace(device, nbytes: int) -> torch.Tensor:
-    """Grow (never shrink) the per-device split-KV scratch.  Call before graph capture with the largest
-    shape; all layers share it (they run back to back on one stream, so it stays hot in L2)."""
+    """Grow (never shrink) the per-device decode scratch.  Call before graph capture with the largest shape; all layers
+    share it (they run back to back on one stream).  ZERO-FILLED: its first 64 KiB are the arrival tickets of the chunked
+    decode kernel, which must read zero before the first launch and are returned to zero by every launch."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     ws = _workspaces.get(idx)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and torch.cuda.is_current_stream_capturing():
-            return torch.empty(nbytes, dtype=torch.uint8, device=device)   # graph-pool memory, not cached
-        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+            return torch.zeros(nbytes, dtype=torch.uint8, device=device)   # graph-pool memory, not cached
+        ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         if not torch.cuda.is_current_stream_capturing():
             _workspaces[idx] = ws
     return ws
@@ -117,18 +118,23 @@ def _decode_common(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scal
 
 
 def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale=None, causal=True,
-                            out=None, out_dtype=None):
+                            out=None, out_dtype=None, out_packed=None):
     """Decode attention, drop-in for the call at attention.py:99-101.
 
     q [B, 1, H, D] (or [B, H, D]); caches [NB, bs, KVH, D]; cache_seqlens int32 [B] (0 -> zero row);
     block_table int32 [B, max_blocks].  `causal` is accepted for signature parity; with one query per
-    sequence it has no effect.  Returns [B, 1, H, D] (or [B, H, D])."""
+    sequence it has no effect.  Returns [B, 1, H, D] (or [B, H, D]).  out_packed: optional flat bf16 buffer of
+    ceil(B/16)*16*H*D elements that also receives the result in MFMA-fragment order (pack_rows layout) for fused_linear."""
     squeeze, q3, b, h, hd, kvh, bs, max_blocks, scale, out, ws = _decode_common(
         q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype)
-    rc = _lib.load().nvh_paged_decode(out.data_ptr(), q3.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
-                                      block_table.data_ptr(), cache_seqlens.data_ptr(), b, h, kvh, hd, bs, max_blocks,
-                                      q3.stride(0), block_table.stride(0), scale, NVH_BF16, _out_code(out.dtype),
-                                      ws.data_ptr(), ws.numel(), _stream())
+    tail = (q3.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_table.data_ptr(), cache_seqlens.data_ptr(), b, h, kvh, hd, bs,
+            max_blocks, q3.stride(0), block_table.stride(0), scale, NVH_BF16, _out_code(out.dtype), ws.data_ptr(), ws.numel(), _stream())
+    if out_packed is not None:
+        _require_gpu_bf16(out_packed=out_packed)
+        assert out_packed.is_contiguous() and out_packed.numel() >= ((b + 15) // 16) * 16 * h * hd
+        rc = _lib.load().nvh_paged_decode_packed(out.data_ptr(), out_packed.data_ptr(), *tail)
+    else:
+        rc = _lib.load().nvh_paged_decode(out.data_ptr(), *tail)
     _lib.check(rc, "nvh_paged_decode")
     return out.unsqueeze(1) if squeeze else out
 

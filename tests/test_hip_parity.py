@@ -405,3 +405,23 @@ def test_config5_prefill_256x128(ops):
         assert np.abs(out[sl].cpu().numpy() - exp).max() <= ATOL
         alone = ops.flash_attn_varlen_func(q[sl], k[sl], v[sl], S, dev_i32(cu1), S, dev_i32(cu1), out_dtype=torch.float32)
         assert torch.equal(alone, out[sl])
+
+
+@pytest.mark.gpu
+def test_decode_packed_output_matches_row_major():
+    """nvh_paged_decode_packed: the fragment-order copy is the row-major bf16 output, element for element (incl. ctx 0 rows)."""
+    from nanovllm_hip import ops
+    torch.manual_seed(3)
+    B, H, KVH, D, bs, nblk = 20, 14, 2, 64, 256, 5
+    ctxs = torch.tensor([1, 0, 255, 256, 257, 700, 1280, 64, 1000, 513] * 2, dtype=torch.int32)
+    kc = torch.randn(B * nblk + 1, bs, KVH, D, device="cuda", dtype=torch.bfloat16)
+    vc = torch.randn_like(kc)
+    bt = torch.randperm(B * nblk)[: B * nblk].view(B, nblk).int().cuda()
+    q = torch.randn(B, H, D, device="cuda", dtype=torch.bfloat16)
+    packed = torch.full((32 * H * D,), 7.0, dtype=torch.bfloat16, device="cuda")
+    o = ops.flash_attn_with_kvcache(q, kc, vc, ctxs.cuda(), bt, out_packed=packed)
+    o_ref = ops.flash_attn_with_kvcache(q, kc, vc, ctxs.cuda(), bt)
+    torch.cuda.synchronize()
+    assert torch.equal(o, o_ref)
+    assert torch.equal(ops.unpack_rows(packed, B, H * D), o.view(B, H * D))
+    assert (o[1] == 0).all()

@@ -33,7 +33,7 @@ def main():
     q = torch.randn(b, h, d, device="cuda", dtype=torch.bfloat16)
     out = torch.empty_like(q)
     nsplit = (nblk * bs + 255) // 256
-    ws = torch.empty(b * h * nsplit * (d + 2) * 4, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(65536 + b * h * nsplit * (d + 2) * 4, dtype=torch.uint8, device="cuda")   # ticket header + partial records
     stamps = torch.zeros(b * kvh * nsplit * 32, dtype=torch.int64, device="cuda")
     lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     lib.nvh_paged_decode.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -45,12 +45,19 @@ def main():
         for l in range(layers): call(l)
     torch.cuda.synchronize()
     st = stamps.cpu().numpy().reshape(-1, 4, 8).astype(np.float64) * 0.01     # us
+    st = st[st[:, 0, 1] > 0]                                                   # live workgroups only
     t0 = st[:, :, 0].min()
-    names = ["start", "scalars+branch", "loads issued", "K landed (vmcnt 8)", "QK+softmax done", "V landed (vmcnt 0)", "PV done", "epilogue+merge done"]
-    print(f"workgroups {st.shape[0]}, kernel span {st[:, :, 7].max() - t0:.2f} us (first wave start -> last wave end)")
+    names = ["start", "scalars+branch", "first loads issued", "first K landed", "first QK+softmax done", "first V landed", "all passes done",
+             "merged + written (last arriver)"]
+    print(f"live workgroups {st.shape[0]}, kernel span {st[:, :, 7].max() - t0:.2f} us (first wave start -> last wave end)")
     for k, n in enumerate(names):
-        v = st[:, :, k] - t0
-        print(f"  {k} {n:<22} abs: min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}"
-              + ("" if k == 0 else f"   delta vs prev: med {np.median(st[:, :, k] - st[:, :, k-1]):5.2f} max {(st[:, :, k] - st[:, :, k-1]).max():5.2f}"))
+        ok = st[:, :, k] > 0
+        v = (st[:, :, k] - t0)[ok]
+        line = f"  {k} {n:<32} abs: min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}"
+        if k:
+            both = ok & (st[:, :, k - 1] > 0)
+            d = (st[:, :, k] - st[:, :, k - 1])[both]
+            line += f"   delta vs prev: med {np.median(d):5.2f} max {d.max():5.2f}"
+        print(line)
 if __name__ == "__main__":
     main()
