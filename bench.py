@@ -14,7 +14,7 @@ region (it is reported separately, and the bench_my-style figure that includes i
 The K timed steps start at context 1025 as bench_my's decode phase does (K = 1024 covers 1025 -> 2048).
 
 Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      the decode attention op (nvh_paged_decode: split-KV attention + combine) at the mean context of the
+  roofline      the decode attention op (nvh_paged_decode: one chunked split-KV launch, combine included) at the mean context of the
                 timed window, timed live with HIP events on the launching stream over a graph of per-layer calls
                 on distinct caches; achieved = algorithmic bytes / average time per call.
   cpu_baseline  the CPU port of the reference's sdpa.math decode (oracle/sdpa_math_cpu.py, "port"), timed on
@@ -69,7 +69,7 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     out = torch.empty(batch, h, d, device=dev, dtype=torch.bfloat16)
     ops.reserve_workspace(dev, ops.decode_workspace_bytes(batch, h, d, nblk, bs))
 
-    def calls():                                   # exactly what a decoder layer launches for attention at decode: split + combine
+    def calls():                                   # exactly what a decoder layer launches for attention at decode
         for c in caches:                           # (the K/V store rides in the qkv projection's epilogue, nvh_linear_small_m_ex)
             ops.flash_attn_with_kvcache(q, c[0], c[1], cl, bt, out=out)
 
@@ -232,7 +232,7 @@ def main():
                        "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(cfg, tp, args.batch, mean_ctx),
-                         "kernel": "one decode attention call (nvh_paged_decode) = paged_decode_split_mfma (dominant) + paged_decode_combine",
+                         "kernel": "one decode attention call (nvh_paged_decode) = one launch of paged_decode_chunked_kernel (split-KV passes + last-arriver combine)",
                          "bytes_per_launch": attn_bytes, "us_per_launch": round(attn_us, 2), "context": mean_ctx,
                          "shape_per_rank": list(shape_rank)},
             "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),
