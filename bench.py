@@ -160,10 +160,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hip attention backend has no CPU path")
+    # NVH_BENCH_REHEARSE=gloo: all ranks share cuda:0 and talk over gloo — a dry run of the N>1 code path (sharding, per-rank
+    # kernel shapes, capture fallback) on a one-GPU box; numbers from it mean nothing and the line says so
+    rehearse = os.environ.get("NVH_BENCH_REHEARSE") == "gloo"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from nanovllm_hip.engine.llm_engine import LLMEngine
     from nanovllm_hip.engine.sequence import Sequence
@@ -174,7 +182,7 @@ def main():
     total_len = args.input_len + args.steps + args.warmup + 2
     blocks_per_seq = (total_len + bs - 1) // bs
     engine = LLMEngine(cfg, num_kvcache_blocks=args.batch * blocks_per_seq + 8, max_model_len=max(4096, total_len),
-                       enforce_eager=args.eager, seed=0)
+                       enforce_eager=args.eager, seed=0, warmup=True)     # start-up warmup as the reference (model_runner.py:107-121)
 
     seed(0)
     prompts = [[randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.batch)]
@@ -226,7 +234,7 @@ def main():
                       else f"decode tok/s (bench_my.py-shaped) {args.model} bs={args.batch}",
             "value": round(tok_s, 1), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random prompts randint(0,10000) seed 0; random-init weights N(0,0.02) seed 0)",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random prompts randint(0,10000) seed 0; random-init weights N(0,0.02) seed 0)" + (" REHEARSAL over gloo on one GPU: not a measurement" if rehearse else ""),
             "config": {"workload": f"{args.model} bs={args.batch} in={args.input_len} decode steps={args.steps} --attn-backend hip, "
                                    f"TP={tp}, {'HIP-graph replay' if sess.graph is not None else 'eager steps (graph capture unavailable)'}, device-resident metadata",
                        "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}"},

@@ -15,13 +15,15 @@ from .sequence import Sequence
 
 class LLMEngine:
     def __init__(self, cfg: ModelConfig, num_kvcache_blocks, max_num_batched_tokens=16384, max_num_seqs=512,
-                 max_model_len=4096, enforce_eager=False, device=None, seed=0):
+                 max_model_len=4096, enforce_eager=False, device=None, seed=0, warmup=False):
         self.cfg = cfg
         self.max_num_batched_tokens = max_num_batched_tokens
         self.max_num_seqs = max_num_seqs
         self.enforce_eager = enforce_eager
         self.runner = ModelRunner(cfg, num_kvcache_blocks, device=device, max_model_len=max_model_len, seed=seed)
         self.block_manager = BlockManager(num_kvcache_blocks, cfg.kvcache_block_size)
+        if warmup:                                                   # the reference always warms up (model_runner.py:52)
+            self.runner.warmup_model(max_num_batched_tokens, max_num_seqs)
 
     def prefill(self, seqs, reserve_tokens):
         """Run every waiting sequence through prefill in FCFS batches; appends the first generated token."""

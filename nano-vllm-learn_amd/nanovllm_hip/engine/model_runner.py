@@ -16,6 +16,8 @@ Mirrors nanovllm/engine/model_runner.py for the parts that produce attention inp
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -104,13 +106,22 @@ class ModelRunner:
     def _dev(self, t):
         return t.to(self.device, non_blocking=True) if t is not None else None
 
+    def warmup_model(self, max_num_batched_tokens=16384, max_num_seqs=512):
+        """One maximum-size prefill of dummy sequences without cache slots, as the reference does at start-up
+        (engine/model_runner.py:107-121): loads every kernel, lets the GEMM library pick its solutions and sizes the
+        allocator's pools, so that the first real prefill is not a cold start."""
+        num_seqs = max(1, min(max_num_batched_tokens // self.max_model_len, max_num_seqs))
+        self.run([Sequence([0] * self.max_model_len) for _ in range(num_seqs)], True)
+        torch.cuda.synchronize(self.device)
+
     @torch.inference_mode()
     def run(self, seqs, is_prefill):
         """One eager forward (prefill, or a decode step with host-built metadata); returns greedy token ids."""
         m = build_prefill_meta(seqs, self.block_size) if is_prefill else build_decode_meta(seqs, self.block_size)
         if is_prefill:
+            slots = m["slot_mapping"] if m["slot_mapping"].numel() else None          # warmup: nothing to store
             set_context(True, self._dev(m["cu_seqlens_q"]), self._dev(m["cu_seqlens_k"]), m["max_seqlen_q"], m["max_seqlen_k"],
-                        self._dev(m["slot_mapping"]), None, self._dev(m["block_tables"]))
+                        self._dev(slots), None, self._dev(m["block_tables"]))
         else:
             set_context(False, slot_mapping=self._dev(m["slot_mapping"]), context_lens=self._dev(m["context_lens"]),
                         block_tables=self._dev(m["block_tables"]))
@@ -124,6 +135,26 @@ class ModelRunner:
 
     def decode_session(self, seqs, max_new_tokens, use_graph=True):
         return DecodeSession(self, seqs, max_new_tokens, use_graph)
+
+
+def _force_end_capture(stream):
+    """Best effort: hipStreamEndCapture on `stream` through the HIP runtime torch already loaded.  Measured on ROCm 7.2 with
+    an uncapturable (gloo) collective: the runtime answers 908 and the stream stays invalidated, so this does not rescue that
+    case — which is why DecodeSession does not attempt capture with non-RCCL backends in the first place."""
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so.7")                 # already mapped by torch: same runtime instance
+        g = ctypes.c_void_p()
+        hip.hipStreamEndCapture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(g))
+        if g.value:
+            hip.hipGraphDestroy(g)
+        hip.hipGetLastError()
+    except (OSError, AttributeError):
+        pass
+    try:
+        torch.cuda.synchronize()
+    except Exception:
+        pass
 
 
 class DecodeSession:
@@ -157,6 +188,9 @@ class DecodeSession:
         h = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, runner.world_size, runner.rank)[1]
         ops.reserve_workspace(dev, ops.decode_workspace_bytes(b, h, cfg.head_dim, self.block_tables.shape[1], bs))
         self.graph = None
+        if use_graph and runner.world_size > 1 and dist.get_backend() != "nccl" and not os.environ.get("NVH_TRY_CAPTURE"):
+            use_graph = False                                 # only RCCL collectives can be captured; anything else runs eager steps
+                                                              # (NVH_TRY_CAPTURE=1: attempt anyway, to exercise the recovery path)
         if use_graph:
             try:
                 self._capture()
@@ -164,7 +198,7 @@ class DecodeSession:
                 import warnings
                 warnings.warn(f"HIP-graph capture of the decode step failed ({type(e).__name__}: {e}); running eager steps")
                 self.graph = None
-                torch.cuda.synchronize()
+                self._restore(self._capture_saved)
 
     def _advance(self, next_tokens):
         """Device-side postprocess + prepare_decode for the following step."""
@@ -190,27 +224,37 @@ class DecodeSession:
             self._advance(greedy_tokens(logits))
         reset_context()
 
+    def _live(self):
+        return (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx, self.row_steps)
+
+    def _restore(self, saved):
+        for t, s in zip(self._live(), saved):
+            t.copy_(s)
+
     @torch.inference_mode()
     def _capture(self):
         # capture must not disturb the live state: snapshot, warm up + capture, restore
-        live = (self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.tokens, self.step_idx, self.row_steps)
-        saved = [t.clone() for t in live]
+        self._capture_saved = saved = [t.clone() for t in self._live()]
+        stream = torch.cuda.Stream(device=self.runner.device)
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            self._step()                                      # warm-up on the side stream (allocator, hipBLASLt heuristics)
+        torch.cuda.current_stream().wait_stream(stream)
+        torch.cuda.synchronize()
+        self.step_idx.zero_()
+        self.row_steps.zero_()
+        graph = torch.cuda.CUDAGraph()
+        cap_stream = torch.cuda.Stream(device=self.runner.device)
         try:
-            stream = torch.cuda.Stream(device=self.runner.device)
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                self._step()                                  # warm-up on the side stream (allocator, hipBLASLt heuristics)
-            torch.cuda.current_stream().wait_stream(stream)
-            torch.cuda.synchronize()
-            self.step_idx.zero_()
-            self.row_steps.zero_()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with torch.cuda.graph(graph, stream=cap_stream):
                 self._step()
-            self.graph = graph
-        finally:
-            for t, s in zip(live, saved):
-                t.copy_(s)
+        except Exception:
+            # a failed capture can leave the stream in the invalidated-capture state, in which every later call fails
+            # ("operation failed due to a previous error during capture"): end it by hand, drop the sticky error, then re-raise
+            _force_end_capture(cap_stream)
+            raise
+        self.graph = graph
+        self._restore(saved)
         # the KV rows the warm-up/capture steps wrote lie beyond the live context and are overwritten by real steps
 
     @torch.inference_mode()
