@@ -37,9 +37,9 @@ def _digest():
     return h.hexdigest()
 
 
-def _compile(src, asm):
-    obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
-    flags = [*FLAGS, *FILE_FLAGS.get(src, [])]
+def _compile(src, asm, extra=(), obj_dir=None):
+    obj = os.path.join(obj_dir or OBJ_DIR, src.replace(".hip", ".o"))
+    flags = [*FLAGS, *FILE_FLAGS.get(src, []), *extra]
     cmd = [HIPCC, *flags, "-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.run(cmd, check=True)
     if asm:
@@ -71,12 +71,28 @@ def build(force=False, asm=False, verbose=True):
     return LIB
 
 
+def build_variant(out, extra):
+    """A/B builds: the same sources with extra compiler flags into another file (select it with NVH_LIB_PATH)."""
+    obj_dir = os.path.join(OBJ_DIR, "variant_" + os.path.basename(out))
+    os.makedirs(obj_dir, exist_ok=True)
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(lambda s: _compile(s, False, extra, obj_dir), SOURCES))
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs], check=True)
+    print(f"[nvh build] built variant {out} with {' '.join(extra)}")
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--asm", action="store_true", help="also emit .s and register/LDS usage per kernel into build/")
+    ap.add_argument("--variant", help="output path of an A/B build with --extra flags (the default library is untouched)")
+    ap.add_argument("--extra", nargs="*", default=[], help="extra hipcc flags of the variant, e.g. =-DNVH_DMA_AUX=2 (leading '=' keeps argparse off them)")
     args = ap.parse_args()
     try:
+        if args.variant:
+            build_variant(args.variant, [e.lstrip("=") for e in args.extra])
+            sys.exit(0)
         build(force=args.force, asm=args.asm)
     except subprocess.CalledProcessError as e:
         sys.exit(e.returncode)

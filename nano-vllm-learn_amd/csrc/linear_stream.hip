@@ -23,6 +23,10 @@
 // atomic add); the workgroup whose add came last reads all partials with `sc1` loads (relaxed agent-scope atomic loads) after
 // a workgroup barrier the ticket holder joins.  A release/acquire fence pair here cost 4-5 us per launch (whole-L2
 // write-back + invalidate under 280 workgroups; profiles/r01_gemm_phase_stamps.txt).
+#ifndef NVH_DMA_AUX
+#define NVH_DMA_AUX 2        // cache policy of the once-read LDS-DMA streams (weights, K/V): 2 = nt, 0 = default.
+                             // nt measured -4.7 % on the decode step, -0.6 us per attention call (same box A/B, round 1)
+#endif
 #include "common.h"
 #include "kernels.h"
 
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
                         const int row = 8 * hh + dr;
                         const uint16_t* src = a.w + (int64_t)((nb == 0 ? n0 : n1) + row) * a.K + (p0 + pi) * 64 + (dp ^ ((row >> 1) & 7)) * 8;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                         (__attribute__((address_space(3))) void*)(stage + ((pi * NB + nb) * 2 + hh) * 1024), 16, 0, 0);
+                                                         (__attribute__((address_space(3))) void*)(stage + ((pi * NB + nb) * 2 + hh) * 1024), 16, 0, NVH_DMA_AUX);
                     }
             }
         }

@@ -30,6 +30,10 @@
 // entries past ceil(ctx/bs) are never used, cache offsets are 64-bit.
 #include <stdlib.h>
 
+#ifndef NVH_DMA_AUX
+#define NVH_DMA_AUX 2        // cache policy of the once-read LDS-DMA streams (weights, K/V): 2 = nt, 0 = default.
+                             // nt measured -4.7 % on the decode step, -0.6 us per attention call (same box A/B, round 1)
+#endif
 #include "common.h"
 #include "kernels.h"
 
@@ -548,14 +552,14 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const Dec
             const int T = i * TPI + dr;
             const int Tc = T < last ? T : last;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.k_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
-                                             (__attribute__((address_space(3))) void*)(kimg + i * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(kimg + i * 1024), 16, 0, NVH_DMA_AUX);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int T = i * TPI + dr;
             const int Tc = T < last ? T : last;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
-                                             (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, NVH_DMA_AUX);
         }
     };
 
