@@ -5,7 +5,8 @@
 //                   bottom-right aligned causal mask; parity unpinned by the reference)
 //
 // Dense contraction -> MFMA (v_mfma_f32_16x16x32_bf16), flash-style online softmax, fp32 accumulate.
-// Workgroup = 4 waves = a tile of BM = 64 query rows of one (sequence, q head); wave w owns rows 16w..16w+15.
+// Workgroup = 4 waves = a tile of BM = 64*QT query rows of one (sequence, q head); wave w owns rows 16*QT*w .. +16*QT-1 as QT
+// sub-tiles of 16 rows (QT = 1 shipped; with QT = 2 every K / V fragment read from LDS feeds both sub-tiles' MFMAs).
 // K/V tiles of BN = 64 keys are staged through LDS by LDS-DMA (global_load_lds_dwordx4: one instruction = 1 KiB of
 // whole, coalesced key rows, no VGPR round trip), DOUBLE-BUFFERED: the DMA of tile i+1 is in flight while tile i is
 // computed; waves wait with a counted vmcnt and meet at raw s_barriers (a __syncthreads() would drain the prefetch).
@@ -45,13 +46,18 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         if (a.stamps && tid == 0 && (k) < 32)                                                            \
-            a.stamps[(((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 32 + (k)] = t_; \
+            a.stamps[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + (gridDim.z - 1 - blockIdx.z)) * 32 + (k)] = t_; \
     } while (0)
 #else
 #define PF_STAMP(k) do {} while (0)
 #endif
 
-constexpr int BM = 64;      // query rows per workgroup
+#ifndef NVH_PREFILL_QT
+#define NVH_PREFILL_QT 1
+#endif
+constexpr int QT = NVH_PREFILL_QT;   // 16-row query sub-tiles per wave: every K / V fragment read from LDS feeds QT MFMAs
+                                     // (QT = 2 measured SLOWER: 180 vs 207 TFLOP/s at S=1024 — the kernel is not LDS-bound)
+constexpr int BM = 64 * QT; // query rows per workgroup (4 waves x QT x 16)
 constexpr int BN = 64;      // keys per LDS tile
 
 // ds_read_b64_tr_b16 through inline asm: the builtin form makes hipcc wait vmcnt(0) before the read (it cannot prove the read
@@ -64,6 +70,12 @@ __device__ __forceinline__ u32x2 ds_read_tr16_b64_asm(uint32_t lds_addr) {
 }
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// one v_max3_f32: plain fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max x,x before every use
+__device__ __forceinline__ float max3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
 }
 
 template <int LPT>
@@ -82,9 +94,14 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     constexpr int STEPS = D / 32;                    // k-steps of the QK^T contraction
     constexpr int DT = D / 16;                       // 16-dim output tiles
     constexpr int NT = BN / 16;                      // 16-key tiles of S^T per LDS tile
+    constexpr int WR = 16 * QT;                      // query rows per wave
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * IMG];     // [buffer][K | V]
 
-    const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    // grid (H, B, q-tiles): workgroups are dispatched x-fastest, so the q-tile index is the SLOW dimension and runs backwards:
+    // under the causal mask tile t costs t+1 key tiles, and dispatching the heaviest tiles of every (sequence, head) first
+    // leaves the light ones for the tail (census in tools/probes/stamp_prefill.py: the old x = q-tile order spent the last
+    // 40 % of the launch draining a few heavy workgroups that had started late)
+    const int qt = gridDim.z - 1 - blockIdx.z, head = blockIdx.x, b = blockIdx.y;
     const int q_beg = a.cu_q[b], q_end = a.cu_q[b + 1];
     const int k_beg = a.cu_k[b], k_end = a.cu_k[b + 1];
     const int sq = q_end - q_beg, sk = k_end - k_beg;
@@ -100,32 +117,40 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     const int lg = lane >> 4;                        // lane group: k-block of the operands / key rows of C
 
     // ---- Q fragments (B operand of S^T): Q[row][32*step + 8*lg .. +8]; plain loads, retired before any DMA is issued
-    const int my_q = q0 + wave * 16 + lq;            // query index inside the sequence
-    const bool q_ok = my_q < sq;
-    bf16x8 qf[STEPS];
-    {
-        const uint16_t* qp = a.q + (int64_t)(q_beg + (q_ok ? my_q : sq - 1)) * a.q_row_stride + (int64_t)head * D + lg * 8;
+    int my_q[QT];                                    // query index inside the sequence, per sub-tile
+    bool q_ok[QT];
+    bf16x8 qf[QT][STEPS];
+#pragma unroll
+    for (int qs = 0; qs < QT; ++qs) {
+        my_q[qs] = q0 + wave * WR + 16 * qs + lq;
+        q_ok[qs] = my_q[qs] < sq;
+        const uint16_t* qp = a.q + (int64_t)(q_beg + (q_ok[qs] ? my_q[qs] : sq - 1)) * a.q_row_stride + (int64_t)head * D + lg * 8;
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) {
             const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + st * 32);
-            qf[st] = *reinterpret_cast<const bf16x8*>(&raw);
+            qf[qs][st] = *reinterpret_cast<const bf16x8*>(&raw);
         }
     }
     PF_STAMP(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PF_STAMP(1);
 
-    f32x4 o[DT];
+    f32x4 o[QT][DT];
+    float m_run[QT], l_run[QT];                      // per query column; l_run is this lane group's share
 #pragma unroll
-    for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;            // per query column; l_run is this lane group's share
+    for (int qs = 0; qs < QT; ++qs) {
+        m_run[qs] = -INFINITY;
+        l_run[qs] = 0.f;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[qs][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // keys any row of this workgroup can see: 0 .. min(sk, q0 + BM + shift) - 1
     int kv_end = q0 + BM + shift;
     if (kv_end > sk) kv_end = sk;
     const int n_tiles = (kv_end + BN - 1) / BN;
-    const int q_pos = my_q + shift;                  // last key this lane's query may see
-    const int wave_last_key = q0 + wave * 16 + 15 + shift;   // last key ANY row of this wave may see
+    const int wave_first_key = q0 + wave * WR + shift;            // last key the wave's FIRST row may see
+    const int wave_last_key = wave_first_key + WR - 1;            // last key ANY row of this wave may see
 
     // ---- staging: wave w issues DMA instructions w*NIW .. w*NIW+NIW-1 of the K image and of the V image
     const int dp = lane % LPT, dr = lane / LPT;
@@ -178,65 +203,78 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         const unsigned char* vimg = kimg + IMG;
         const int kv0 = it * BN;
         if (kv0 <= wave_last_key) {                                              // wave-uniform: tile not entirely above the diagonal
-            // ---- S^T for the four 16-key tiles
-            f32x4 sT[NT];
+            // ---- S^T for the four 16-key tiles of both query sub-tiles: each K fragment is read once, used QT times
+            f32x4 sT[QT][NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int qs = 0; qs < QT; ++qs) sT[qs][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 const int R = 16 * tt + lq;
 #pragma unroll
                 for (int st = 0; st < STEPS; ++st) {
                     const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + R * ROWB + (((4 * st + lg) ^ chunk_swz<LPT>(R)) * 16));
-                    sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) sT[qs][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][st], sT[qs][tt], 0, 0, 0);
                 }
             }
             // ---- online softmax in the log2 domain.  Masking only where it can matter: tiles that reach past this wave's
             // first row's diagonal or past the sequence end (wave-uniform test); interior tiles skip the per-element work.
-            const bool need_mask = kv0 + BN - 1 > q0 + wave * 16 + shift || kv0 + BN > sk;
-            if (need_mask) {
+            const bool need_mask = kv0 + BN - 1 > wave_first_key || kv0 + BN > sk;
+#pragma unroll
+            for (int qs = 0; qs < QT; ++qs) {
+                if (need_mask) {
+                    const int q_pos = my_q[qs] + shift;                          // last key this lane's query may see
+#pragma unroll
+                    for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kv0 + 16 * tt + 4 * lg + r;
+                            sT[qs][tt][r] = (key <= q_pos && key < sk) ? sT[qs][tt][r] : -INFINITY;
+                        }
+                }
+                float mx = max3(sT[qs][0][0], sT[qs][0][1], sT[qs][0][2]);
+                mx = max3(mx, sT[qs][0][3], sT[qs][1][0]);
+                mx = max3(mx, sT[qs][1][1], sT[qs][1][2]);
+                mx = max3(mx, sT[qs][1][3], sT[qs][2][0]);
+                mx = max3(mx, sT[qs][2][1], sT[qs][2][2]);
+                mx = max3(mx, sT[qs][2][3], sT[qs][3][0]);
+                mx = max3(mx, sT[qs][3][1], sT[qs][3][2]);
+                mx = fmaxf(mx, sT[qs][3][3]);
+                mx = max_xor16(mx);
+                mx = max_xor32(mx);
+                mx *= a.scale_log2;                                              // scale > 0: max commutes with the scaling
+                const float m_new = fmaxf(m_run[qs], mx);
+                // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
+                const float m_use = m_new == -INFINITY ? 0.f : m_new;
+                float psum = 0.f;
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + 16 * tt + 4 * lg + r;
-                        sT[tt][r] = (key <= q_pos && key < sk) ? sT[tt][r] : -INFINITY;
+                        sT[qs][tt][r] = fast_exp2(fmaf(sT[qs][tt][r], a.scale_log2, -m_use));   // one FMA: scale and subtract the max
+                        psum += sT[qs][tt][r];
                     }
-            }
-            float mx = fmaxf(fmaxf(sT[0][0], sT[0][1]), fmaxf(sT[0][2], sT[0][3]));
+                if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {      // some row's max moved: rescale (wave-uniform branch)
+                    const float alpha = fast_exp2(m_run[qs] - m_use);            // m_run = -inf -> 0
+                    l_run[qs] *= alpha;
 #pragma unroll
-            for (int tt = 1; tt < NT; ++tt) mx = fmaxf(fmaxf(mx, fmaxf(sT[tt][0], sT[tt][1])), fmaxf(sT[tt][2], sT[tt][3]));
-            mx = max_xor16(mx);
-            mx = max_xor32(mx);
-            mx *= a.scale_log2;                                                  // scale > 0: max commutes with the scaling
-            const float m_new = fmaxf(m_run, mx);
-            // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
-            const float m_use = m_new == -INFINITY ? 0.f : m_new;
-            float psum = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    sT[tt][r] = fast_exp2(fmaf(sT[tt][r], a.scale_log2, -m_use));      // one FMA: scale and subtract the max
-                    psum += sT[tt][r];
+                    for (int t = 0; t < DT; ++t) o[qs][t] *= alpha;
                 }
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {              // some row's max moved: rescale (wave-uniform branch)
-                const float alpha = fast_exp2(m_run - m_use);                    // m_run = -inf -> 0
-                l_run *= alpha;
-#pragma unroll
-                for (int t = 0; t < DT; ++t) o[t] *= alpha;
+                l_run[qs] += psum;
+                m_run[qs] = m_new;
             }
-            l_run += psum;
-            m_run = m_new;
-            // ---- O^T += V^T P^T, 32 keys at a time, P as hi + lo bf16
+            // ---- O^T += V^T P^T, 32 keys at a time, P as hi + lo bf16; each V fragment is read once, used 2*QT times
 #pragma unroll
             for (int hh = 0; hh < BN / 32; ++hh) {
-                bf16x8 p_hi, p_lo;
+                bf16x8 p_hi[QT], p_lo[QT];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float pv = sT[2 * hh + (i >> 2)][i & 3];
-                    p_hi[i] = (__bf16)pv;
-                    p_lo[i] = (__bf16)(pv - (float)p_hi[i]);
-                }
+                for (int qs = 0; qs < QT; ++qs)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float pv = sT[qs][2 * hh + (i >> 2)][i & 3];
+                        p_hi[qs][i] = (__bf16)pv;
+                        p_lo[qs][i] = (__bf16)(pv - (float)p_hi[qs][i]);
+                    }
                 const int R = 32 * hh + 4 * lg + vq;                             // chunk_swz(R) == chunk_swz(R + 16)
                 const uint32_t vrow = lds_offset(vimg + R * ROWB + (vp & 1) * 8);
                 const int swz = chunk_swz<LPT>(R);
@@ -253,8 +291,11 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 for (int t = 0; t < DT; ++t) {
                     const u32x4 raw = {vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&raw);
-                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi, o[t], 0, 0, 0);
-                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo, o[t], 0, 0, 0);
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) {
+                        o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi[qs], o[qs][t], 0, 0, 0);
+                        o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo[qs], o[qs][t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -266,27 +307,30 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
 
     PF_STAMP(31);
     // ---- finalise: total row sum over the 4 lane groups, normalise, store 4 contiguous dims per tile
-    l_run = sum_xor16(l_run);
-    l_run = sum_xor32(l_run);
-    if (!q_ok) return;
-    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-    const int64_t orow = ((int64_t)(q_beg + my_q) * a.h + head) * D;
 #pragma unroll
-    for (int t = 0; t < DT; ++t) {
-        const int d0 = 16 * t + 4 * lg;
-        const f32x4 r = o[t] * inv;
-        if (a.out_f32) {
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + d0) = r;
-        } else {
-            u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
-            *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + orow + d0) = pk;
+    for (int qs = 0; qs < QT; ++qs) {
+        float l = sum_xor16(l_run[qs]);
+        l = sum_xor32(l);
+        if (!q_ok[qs]) continue;
+        const float inv = l > 0.f ? 1.f / l : 0.f;
+        const int64_t orow = ((int64_t)(q_beg + my_q[qs]) * a.h + head) * D;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            const int d0 = 16 * t + 4 * lg;
+            const f32x4 r = o[qs][t] * inv;
+            if (a.out_f32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + d0) = r;
+            } else {
+                u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + orow + d0) = pk;
+            }
         }
     }
 }
 
 template <int D>
 int launch_d(const PrefillArgs& a, hipStream_t stream) {
-    dim3 grid((a.max_seqlen_q + BM - 1) / BM, a.h, a.batch);
+    dim3 grid(a.h, a.batch, (a.max_seqlen_q + BM - 1) / BM);
     if (a.block_tables) hipLaunchKernelGGL((prefill_varlen_kernel<D, true>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((prefill_varlen_kernel<D, false>), grid, dim3(256), 0, stream, a);
     return check_launch("prefill_varlen");

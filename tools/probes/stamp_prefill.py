@@ -40,3 +40,8 @@ span = st[..., 31].max() - t0
 print(f"mean resident workgroups per CU: {life.sum() / span / 256:.2f}  (sum of lives {life.sum():.0f} us over span {span:.1f} us)")
 tiles = sum(qt + 1 for qt in range(nq)) * B * H
 print(f"CU-time per workgroup-tile: {span * 256 / tiles * 1e3:.0f} ns  ({tiles} tiles)")
+# census: workgroups alive at sampled times, and by q-tile
+starts, ends = st[..., 0].ravel() - t0, st[..., 31].ravel() - t0
+for t in np.linspace(0, span, 13)[1:-1]:
+    alive = ((starts <= t) & (ends > t)).sum()
+    print(f"  t = {t:6.1f} us: {alive:5d} workgroups alive ({alive / 256:.2f} per CU), {int((starts > t).sum()):5d} not yet started")
