@@ -26,6 +26,8 @@
 // Causal structure: a workgroup only walks the key tiles its rows can see; a wave skips the MFMA work of tiles that lie
 // entirely above its own 16 rows' diagonal (it still takes part in the staging and the barriers).
 // Algorithmic flops per launch: sum_seq 4*D*H*(causal pairs); bytes: Tq*H*D*2*2 + Tk*KVH*D*2*2.
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -63,9 +65,11 @@ constexpr int BN = 64;      // keys per LDS tile
 // ds_read_b64_tr_b16 through inline asm: the builtin form makes hipcc wait vmcnt(0) before the read (it cannot prove the read
 // does not alias the LDS-DMA of the NEXT tile that is still in flight), which serialised the double buffer.  The caller
 // issues a batch of these, then `s_waitcnt lgkmcnt(0)` + a scheduling fence before the first use (guide rule 18).
+template <int OFF>
 __device__ __forceinline__ u32x2 ds_read_tr16_b64_asm(uint32_t lds_addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
     u32x2 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(lds_addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(lds_addr), "n"(OFF) : "memory");
     return r;
 }
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
@@ -152,43 +156,69 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     const int wave_first_key = q0 + wave * WR + shift;            // last key the wave's FIRST row may see
     const int wave_last_key = wave_first_key + WR - 1;            // last key ANY row of this wave may see
 
-    // ---- staging: wave w issues DMA instructions w*NIW .. w*NIW+NIW-1 of the K image and of the V image
+    // ---- staging: wave w issues DMA instructions w*NIW .. w*NIW+NIW-1 of the K image and of the V image.  Source address =
+    // a wave-uniform base per tile (scalar arithmetic) + a loop-invariant 32-bit lane offset (row of the tile x row stride +
+    // swizzled chunk), so a full tile costs no vector integer work; only the sequence's last, ragged tile re-derives the
+    // lane offsets with its rows clamped to the last key (those rows are masked).
     const int dp = lane % LPT, dr = lane / LPT;
+    const int64_t kstride = PAGED ? (int64_t)a.kvh * D : a.k_row_stride;
+    const int64_t vstride = PAGED ? (int64_t)a.kvh * D : a.v_row_stride;
+    uint32_t koff[NIW], voff[NIW];
+#pragma unroll
+    for (int j = 0; j < NIW; ++j) {
+        const int R = (wave * NIW + j) * TPI + dr;
+        const int ch = (dp ^ chunk_swz<LPT>(R)) * 8;
+        koff[j] = (uint32_t)(R * kstride + ch);
+        voff[j] = (uint32_t)(R * vstride + ch);
+    }
     auto stage = [&](int tile, int buf) {
         unsigned char* kimg = lds + buf * 2 * IMG;
         unsigned char* vimg = kimg + IMG;
         const int kv0 = tile * BN;
-        int64_t blk_base = 0;
-        if constexpr (PAGED) {                       // BN divides block_size: one block per tile, wave-uniform id
+        const uint16_t *kb, *vb;                     // wave-uniform bases of the tile's first key row, this kv head
+        if constexpr (PAGED) {                       // BN divides block_size: one block per tile
             const int blk = kv0 / a.block_size;
             const int bid = a.block_tables[(int64_t)b * a.bt_row_stride + blk];
-            blk_base = ((int64_t)bid * a.block_size + (kv0 - blk * a.block_size)) * a.kvh;
+            const int64_t base = (((int64_t)bid * a.block_size + (kv0 - blk * a.block_size)) * a.kvh + kh) * D;
+            kb = a.k + base;
+            vb = a.v + base;
+        } else {
+            kb = a.k + (int64_t)(k_beg + kv0) * kstride + (int64_t)kh * D;
+            vb = a.v + (int64_t)(k_beg + kv0) * vstride + (int64_t)kh * D;
         }
+        const bool ragged = kv0 + BN > sk;           // wave-uniform
 #pragma unroll
         for (int j = 0; j < NIW; ++j) {
             const int ins = wave * NIW + j;
-            const int R = ins * TPI + dr;                                        // row of the tile
-            const int key = kv0 + R < sk ? kv0 + R : sk - 1;                     // rows past the sequence repeat its last key (masked)
-            const int ch = (dp ^ chunk_swz<LPT>(R)) * 8;
-            int64_t koff, voff;
-            if constexpr (PAGED) {
-                koff = (blk_base + (int64_t)(key - kv0) * a.kvh + kh) * D + ch;
-                voff = koff;
-            } else {
-                koff = (int64_t)(k_beg + key) * a.k_row_stride + (int64_t)kh * D + ch;
-                voff = (int64_t)(k_beg + key) * a.v_row_stride + (int64_t)kh * D + ch;
+            uint32_t ko = koff[j], vo = voff[j];
+            if (ragged) {
+                const int R = ins * TPI + dr;
+                const int Rc = kv0 + R < sk ? R : sk - 1 - kv0;
+                const int ch = (dp ^ chunk_swz<LPT>(R)) * 8;
+                ko = (uint32_t)(Rc * kstride + ch);
+                vo = (uint32_t)(Rc * vstride + ch);
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.k + koff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko),
                                              (__attribute__((address_space(3))) void*)(kimg + ins * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v + voff),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + vo),
                                              (__attribute__((address_space(3))) void*)(vimg + ins * 1024), 16, 0, 0);
         }
     };
 
     stage(0, 0);
-    const int vq = lq >> 2, vp = lq & 3;             // tr-read: lane 4q+p of its group addresses key row q, dims 4p..4p+3
-    for (int it = 0; it < n_tiles; ++it) {
-        const int buf = it & 1;
+    // tr-read: lane 4q+p of its group addresses key row q, dims 4p..4p+3.  The per-lane part of the address (row 4*lg+q,
+    // swizzled chunk of dim tile t) is loop invariant: DT registers; buffer, image, 32-key half and the +16-row partner are
+    // immediates of the instruction (hence the tile loop unrolled by two: the buffer index must be a compile-time constant).
+    const int vq = lq >> 2, vp = lq & 3;
+    uint32_t vaddr[DT];
+    {
+        const int R0 = 4 * lg + vq;                  // chunk_swz(R0) == chunk_swz(R0 + 16) == chunk_swz(R0 + 32)
+        const int swz = chunk_swz<LPT>(R0);
+#pragma unroll
+        for (int t = 0; t < DT; ++t) vaddr[t] = lds_offset(lds + R0 * ROWB + (vp & 1) * 8 + (((2 * t + (vp >> 1)) ^ swz) * 16));
+    }
+    auto tile_body = [&](auto bufc, const int it) {
+        constexpr int buf = decltype(bufc)::value;
         if (it + 1 < n_tiles) {
             stage(it + 1, buf ^ 1);
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NIW) : "memory");       // tile `it` landed, tile it+1 in flight
@@ -200,7 +230,6 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         asm volatile("" ::: "memory");
         PF_STAMP(3 + 3 * it);
         const unsigned char* kimg = lds + buf * 2 * IMG;
-        const unsigned char* vimg = kimg + IMG;
         const int kv0 = it * BN;
         if (kv0 <= wave_last_key) {                                              // wave-uniform: tile not entirely above the diagonal
             // ---- S^T for the four 16-key tiles of both query sub-tiles: each K fragment is read once, used QT times
@@ -275,15 +304,19 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                         p_hi[qs][i] = (__bf16)pv;
                         p_lo[qs][i] = (__bf16)(pv - (float)p_hi[qs][i]);
                     }
-                const int R = 32 * hh + 4 * lg + vq;                             // chunk_swz(R) == chunk_swz(R + 16)
-                const uint32_t vrow = lds_offset(vimg + R * ROWB + (vp & 1) * 8);
-                const int swz = chunk_swz<LPT>(R);
                 u32x2 vlo[DT], vhi[DT];
+                if (hh == 0) {
 #pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    const uint32_t off = ((2 * t + (vp >> 1)) ^ swz) * 16;
-                    vlo[t] = ds_read_tr16_b64_asm(vrow + off);
-                    vhi[t] = ds_read_tr16_b64_asm(vrow + 16 * ROWB + off);
+                    for (int t = 0; t < DT; ++t) {
+                        vlo[t] = ds_read_tr16_b64_asm<buf * 2 * IMG + IMG>(vaddr[t]);
+                        vhi[t] = ds_read_tr16_b64_asm<buf * 2 * IMG + IMG + 16 * ROWB>(vaddr[t]);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        vlo[t] = ds_read_tr16_b64_asm<buf * 2 * IMG + IMG + 32 * ROWB>(vaddr[t]);
+                        vhi[t] = ds_read_tr16_b64_asm<buf * 2 * IMG + IMG + 48 * ROWB>(vaddr[t]);
+                    }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
@@ -303,6 +336,10 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         PF_STAMP(4 + 3 * it);
         __builtin_amdgcn_s_barrier();                                            // ... and everyone's: tile it+2 may overwrite it
         asm volatile("" ::: "memory");
+    };
+    for (int it = 0; it < n_tiles; it += 2) {
+        tile_body(std::integral_constant<int, 0>{}, it);
+        if (it + 1 < n_tiles) tile_body(std::integral_constant<int, 1>{}, it + 1);
     }
 
     PF_STAMP(31);

@@ -10,7 +10,7 @@ OUT = os.path.join(ROOT, "tools", "probes", "libnvh_attn_stamps.so")
 
 def build():
     srcs = [os.path.join(CSRC, f) for f in ("api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNVH_STAMPS", "-ffp-contract=off",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNVH_STAMPS", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
                     "-Wno-unused-command-line-argument", *srcs, "-o", OUT], check=True)
 
 def main():
