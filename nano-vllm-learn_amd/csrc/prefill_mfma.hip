@@ -6,7 +6,7 @@
 //
 // Dense contraction -> MFMA (v_mfma_f32_16x16x32_bf16), flash-style online softmax, fp32 accumulate.
 // Workgroup = 4 waves = a tile of BM = 64*QT query rows of one (sequence, q head); wave w owns rows 16*QT*w .. +16*QT-1 as QT
-// sub-tiles of 16 rows (QT = 1 shipped; with QT = 2 every K / V fragment read from LDS feeds both sub-tiles' MFMAs).
+// sub-tiles of 16 rows (QT = 1 or 2, picked per launch from head_dim and the longest sequence).
 // K/V tiles of BN = 64 keys are staged through LDS by LDS-DMA (global_load_lds_dwordx4: one instruction = 1 KiB of
 // whole, coalesced key rows, no VGPR round trip), DOUBLE-BUFFERED: the DMA of tile i+1 is in flight while tile i is
 // computed; waves wait with a counted vmcnt and meet at raw s_barriers (a __syncthreads() would drain the prefetch).
@@ -54,12 +54,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define PF_STAMP(k) do {} while (0)
 #endif
 
-#ifndef NVH_PREFILL_QT
-#define NVH_PREFILL_QT 1
-#endif
-constexpr int QT = NVH_PREFILL_QT;   // 16-row query sub-tiles per wave: every K / V fragment read from LDS feeds QT MFMAs
-                                     // (QT = 2 measured SLOWER: 180 vs 207 TFLOP/s at S=1024 — the kernel is not LDS-bound)
-constexpr int BM = 64 * QT; // query rows per workgroup (4 waves x QT x 16)
+// QT = 16-row query sub-tiles per wave (template parameter): with QT = 2 every K / V fragment read from LDS feeds both
+// sub-tiles' MFMAs and the per-tile scalar / DMA / barrier work is halved per flop, at half the occupancy.  Measured (lean
+// loop, heaviest-first grid): D=128 +18.5 % (482 -> 571 TFLOP/s at S=4096), D=64 +6.6 % at S=4096, neutral at S=1024.
 constexpr int BN = 64;      // keys per LDS tile
 
 // ds_read_b64_tr_b16 through inline asm: the builtin form makes hipcc wait vmcnt(0) before the read (it cannot prove the read
@@ -87,8 +84,9 @@ __device__ __forceinline__ int chunk_swz(int row) {
     return LPT == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
-template <int D, bool PAGED>
+template <int D, bool PAGED, int QT>
 __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a) {
+    constexpr int BM = 64 * QT;                      // query rows per workgroup (4 waves x QT x 16)
     constexpr int ROWB = D * 2;                      // LDS row, bytes
     constexpr int LPT = D / 8;                       // 16-byte chunks per row
     constexpr int TPI = 64 / LPT;                    // rows per DMA instruction
@@ -365,12 +363,18 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     }
 }
 
+template <int D, int QT>
+int launch_q(const PrefillArgs& a, hipStream_t stream) {
+    dim3 grid(a.h, a.batch, (a.max_seqlen_q + 64 * QT - 1) / (64 * QT));
+    if (a.block_tables) hipLaunchKernelGGL((prefill_varlen_kernel<D, true, QT>), grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT>), grid, dim3(256), 0, stream, a);
+    return check_launch("prefill_varlen");
+}
+
 template <int D>
 int launch_d(const PrefillArgs& a, hipStream_t stream) {
-    dim3 grid(a.h, a.batch, (a.max_seqlen_q + BM - 1) / BM);
-    if (a.block_tables) hipLaunchKernelGGL((prefill_varlen_kernel<D, true>), grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((prefill_varlen_kernel<D, false>), grid, dim3(256), 0, stream, a);
-    return check_launch("prefill_varlen");
+    const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= 2048;
+    return two ? launch_q<D, 2>(a, stream) : launch_q<D, 1>(a, stream);
 }
 
 }  // namespace

@@ -425,3 +425,28 @@ def test_decode_packed_output_matches_row_major():
     assert torch.equal(o, o_ref)
     assert torch.equal(ops.unpack_rows(packed, B, H * D), o.view(B, H * D))
     assert (o[1] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,KVH,D,lens", [(4, 2, 64, (2304, 77, 2049)), (2, 1, 128, (700, 129, 130)), (14, 2, 64, (4096,))])
+def test_prefill_long_sequences_two_subtile_path(H, KVH, D, lens):
+    """Sequences long enough to select the two-sub-tile (QT = 2, 128 query rows per workgroup) prefill kernel, ragged lengths
+    in one varlen batch, against a torch fp32 reference of causal softmax(QK^T/sqrt(D))V on the same bf16 inputs (the
+    oracle's numpy loops are too slow at these sizes; the reference is the same math as attention_sdpa.py:95-113)."""
+    from nanovllm_hip import ops
+    gen = torch.Generator().manual_seed(sum(lens) + D)
+    T = sum(lens)
+    q = torch.randn(T, H, D, generator=gen).bfloat16().cuda()
+    k = torch.randn(T, KVH, D, generator=gen).bfloat16().cuda()
+    v = torch.randn(T, KVH, D, generator=gen).bfloat16().cuda()
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device="cuda")
+    out = ops.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    g = H // KVH
+    for i, n in enumerate(lens):
+        sl = slice(int(cu[i]), int(cu[i + 1]))
+        qf, kf, vf = q[sl].float(), k[sl].float().repeat_interleave(g, dim=1), v[sl].float().repeat_interleave(g, dim=1)
+        s = torch.einsum("qhd,khd->hqk", qf, kf) * D ** -0.5
+        s = s.masked_fill(torch.triu(torch.ones(n, n, dtype=torch.bool, device="cuda"), 1), float("-inf"))
+        ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), vf)
+        assert (out[sl] - ref).abs().max().item() <= ATOL
