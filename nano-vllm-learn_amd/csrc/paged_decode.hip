@@ -289,6 +289,13 @@ __device__ __forceinline__ u32x2 ds_read_tr16_b64_asm(uint32_t lds_addr) {
 __device__ __forceinline__ uint32_t lds_offset(const void* p) {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
+// one v_max3_f32: plain fmaxf on MFMA outputs makes hipcc emit a canonicalising v_max x,x before every use
+__device__ __forceinline__ float max3(float x, float y, float z) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+
 // wave-uniform int32 load through the constant address space: stays a scalar load (lgkmcnt) inside loops that also hold
 // stores and LDS-DMA, where a plain load would be a vector load whose vmcnt wait drains the DMA queue
 __device__ __forceinline__ int32_t load_uniform_i32(const int32_t* p) {
@@ -614,32 +621,38 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const Dec
                     sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
                 }
             }
-            // ---- online softmax (log2 domain): tile max per head, rescale of the running sums
-            float mx = -INFINITY;
+            // ---- online softmax (log2 domain): tile max per head on the RAW scores (scale > 0 commutes with max), scale and
+            // max subtraction in one FMA inside the exp2; masking only on a ragged tile; rescale only when a max moved
+            if (n_live < WT) {                                 // wave-uniform: the context ends inside this tile
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
+                for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool live = 16 * tt + 4 * lg + r < n_live;
-                    sT[tt][r] = live ? sT[tt][r] * a.scale_log2 : -INFINITY;
-                    mx = fmaxf(mx, sT[tt][r]);
-                }
+                    for (int r = 0; r < 4; ++r)
+                        if (16 * tt + 4 * lg + r >= n_live) sT[tt][r] = -INFINITY;
+            }
+            float mx = sT[0][0];
+#pragma unroll
+            for (int i = 1; i + 1 < 4 * NT; i += 2) mx = max3(mx, sT[i >> 2][i & 3], sT[(i + 1) >> 2][(i + 1) & 3]);
+            mx = fmaxf(mx, sT[NT - 1][3]);
             mx = max_xor16(mx);
             mx = max_xor32(mx);                                // finite: token 0 of the tile is live
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = fast_exp2(m_run - m_new);     // first pass: exp2(-inf) = 0
-            m_run = m_new;
+            const float m_new = fmaxf(m_run, mx * a.scale_log2);
             float lsum = 0.f;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    sT[tt][r] = fast_exp2(sT[tt][r] - m_new);
+                    sT[tt][r] = fast_exp2(fmaf(sT[tt][r], a.scale_log2, -m_new));
                     lsum += sT[tt][r];
                 }
-            l_run = fmaf(l_run, alpha, lsum);                 // per-lane partial sums; alpha is uniform over a head's lanes
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {             // wave-uniform branch; always taken on the first pass
+                const float alpha = fast_exp2(m_run - m_new);                   // first pass: exp2(-inf) = 0
+                l_run *= alpha;                                // per-lane partial sums; alpha is uniform over a head's lanes
 #pragma unroll
-            for (int t = 0; t < DT; ++t) o[t] = o[t] * alpha;
+                for (int t = 0; t < DT; ++t) o[t] = o[t] * alpha;
+            }
+            l_run += lsum;
+            m_run = m_new;
             if (pass == split) NVH_STAMP(4);
             if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");   // this pass's V landed
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -667,13 +680,17 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const Dec
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                bf16x8 vf[DT];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
                     const u32x4 raw = {vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&raw);
-                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi, o[t], 0, 0, 0);
-                    o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo, o[t], 0, 0, 0);
+                    vf[t] = *reinterpret_cast<const bf16x8*>(&raw);
                 }
+                // all hi products, then all lo: the two MFMAs on one accumulator are DT-1 independent MFMAs apart
+#pragma unroll
+                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], p_hi, o[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], p_lo, o[t], 0, 0, 0);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                      // image reads done: the buffer may be refilled
             if (!has_next) break;

@@ -318,16 +318,21 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                bf16x8 vf[DT];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
                     const u32x4 raw = {vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
-                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(&raw);
-#pragma unroll
-                    for (int qs = 0; qs < QT; ++qs) {
-                        o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_hi[qs], o[qs][t], 0, 0, 0);
-                        o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, p_lo[qs], o[qs][t], 0, 0, 0);
-                    }
+                    vf[t] = *reinterpret_cast<const bf16x8*>(&raw);
                 }
+                // all hi products, then all lo: the two MFMAs on one accumulator are QT*DT-1 independent MFMAs apart
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], p_hi[qs], o[qs][t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int qs = 0; qs < QT; ++qs) o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], p_lo[qs], o[qs][t], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's LDS reads of buffer `buf` are done
