@@ -1,0 +1,19 @@
+# SQ counters of the shipped prefill and decode attention kernels (one rocprofv3 --pmc pass per counter set)
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+sets=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES GRBM_GUI_ACTIVE" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM" "SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM")
+run() {  # $1 = kernel substring, rest = program args
+  k=$1; shift; i=0
+  for set in "${sets[@]}"; do
+    i=$((i+1))
+    timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmcf_$i -- python3 tools/microbench.py "$@" --iters 3 --warmup 1 > gpurun_out/pmcf_$i.log 2>&1
+    f=$(ls gpurun_out/pmcf_$i/*/*counter_collection.csv 2>/dev/null | head -1)
+    if [ -n "$f" ]; then python3 tools/pmc_kernel.py $f $k; else tail -3 gpurun_out/pmcf_$i.log; fi
+    rm -rf gpurun_out/pmcf_$i
+  done
+}
+echo "# prefill_varlen_kernel<64,false,1>  B=16 S=1024 H/KVH/D=14/2/64 (sums over the chip; SQ_*_CYCLES / ACTIVE / WAIT in quad-cycles, MFMA_BUSY in cycles)"
+run prefill_varlen prefill --batch 16 --seq 1024
+echo "# prefill_varlen_kernel<128,false,2> B=4 S=4096 H/KVH/D=16/8/128"
+run prefill_varlen prefill --batch 4 --seq 4096 --heads 16 --kv-heads 8 --head-dim 128
+echo "# paged_decode_chunked_kernel<64>  B=32 ctx=1536 width 16 (eager launches)"
+run paged_decode_chunked decode --batch 32 --ctx 1536 --width 16
