@@ -170,6 +170,25 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
             resid[j] = row < a.M ? reinterpret_cast<const uint16_t*>(a.out)[(int64_t)row * a.out_stride + tile_first * 16 + (l & 15)] : (uint16_t)0;
         }
     }
+    // RoPE epilogue operands of the same elements (bias pair, cos, sin, cache slot): two dependent loads deep
+    // (positions[row] -> cos_sin row), fetched here so that they travel while W is in flight
+    float rp_b1[MT], rp_b2[MT], rp_co[MT], rp_si[MT];
+    int rp_slot[MT];
+    if constexpr (EPI == EPI_ROPE && !MULTI) {
+        int n0, n1, head, hi0;
+        tile_rows(tile_first, n0, n1, head, hi0);
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int v = tid + 256 * j, l = (v >> 2) & 63, c = l & 15;
+            const int row = min(16 * (v >> 8) + 4 * (l >> 4) + (v & 3), a.M - 1);
+            rp_b1[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f;
+            rp_b2[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n1 + c]) : 0.f;
+            const float* cs = a.cos_sin + a.positions[row] * a.hd;
+            rp_co[j] = cs[hi0 + c];
+            rp_si[j] = cs[a.hd / 2 + hi0 + c];
+            rp_slot[j] = head >= a.h ? a.slots[row] : 0;
+        }
+    }
     LS_STAMP(2);
 
     float ss2[MT];
@@ -338,17 +357,16 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
                 if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.N)] = __builtin_bit_cast(uint16_t, o);
             } else if constexpr (EPI == EPI_ROPE) {
                 float x1 = y[0], x2 = y[1];
-                if (a.bias) {
-                    x1 += (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]);
-                    x2 += (float)__builtin_bit_cast(__bf16, a.bias[n1 + c]);
+                if (a.bias) {                                              // (x + 0.f would also be exact, but keep the no-bias path add-free)
+                    x1 += rp_b1[j];
+                    x2 += rp_b2[j];
                 }
                 x1 = (float)(__bf16)x1;                                    // the projection output is bf16 in the reference
                 x2 = (float)(__bf16)x2;
                 const int i = hi0 + c;                                     // index inside the half head
                 float y1 = x1, y2 = x2;
                 if (head < a.h + a.kvh) {                                  // q or k head: rotate (products and sums rounded separately)
-                    const float* cs = a.cos_sin + a.positions[row] * a.hd;
-                    const float co = cs[i], si = cs[a.hd / 2 + i];
+                    const float co = rp_co[j], si = rp_si[j];
                     const float p1 = x1 * co, p2 = x2 * si, p3 = x2 * co, p4 = x1 * si;
                     y1 = p1 - p2;
                     y2 = p3 + p4;
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
                     q[0] = (__bf16)y1;
                     q[a.hd / 2] = (__bf16)y2;
                 } else {
-                    const int slot = a.slots[row];
+                    const int slot = rp_slot[j];
                     if (slot >= 0) {
                         const bool is_v = head >= a.h + a.kvh;
                         __bf16* dst = reinterpret_cast<__bf16*>(is_v ? a.v_cache : a.k_cache) +

@@ -52,11 +52,17 @@ def run(tag, nwg, fn, ws_list):
             fn(ws_list[0 if warm else l % len(ws_list)])
         report(tag + (" [warm: same weights every call]" if warm else " [cold: weights from HBM]"), nwg)
 
+from nanovllm_hip.models.qwen import cos_sin_table
+w_qkv = copies((H + 2 * KVH) * D, HID)
+b_qkv = torch.randn((H + 2 * KVH) * D, device=dev, dtype=torch.bfloat16)
+cs = cos_sin_table(D, 4096, 1e6, dev)
+pos = torch.randint(0, 4096, (M,), device=dev)
+slots = torch.randperm(8 * 256, device=dev)[:M].int()
+kvc = torch.zeros(2, 8, 256, KVH, D, dtype=torch.bfloat16, device=dev)
+rope = dict(positions=pos, cos_sin=cs, k_cache=kvc[0], v_cache=kvc[1], slot_mapping=slots, num_heads=H, num_kv_heads=KVH, head_dim=D)
 xp = ops.pack_rows(x)
 actp = ops.pack_rows(act)
-run("gate_up  K=896 N=9728 silu folded-norm, row-major x", INTER // 16, lambda w: ops.fused_linear(x, w, norm_folded=True, norm_eps=1e-6, epilogue="silu_mul"), w_gu)
 run("gate_up  same, packed x", INTER // 16, lambda w: ops.fused_linear(xp, w, x_packed_rows=M, norm_folded=True, norm_eps=1e-6, epilogue="silu_mul"), w_gu)
-run("down     K=4864 N=896 residual, split-K 5, row-major x", 5 * HID // 16, lambda w: ops.fused_linear(act, w, epilogue="residual_add", out=res, workspace=ws), w_dn)
 run("down     same, packed x", 5 * HID // 16, lambda w: ops.fused_linear(actp, w, x_packed_rows=M, epilogue="residual_add", out=res, workspace=ws), w_dn)
-run("o_proj   K=896 N=896 residual, row-major x", HID // 16, lambda w: ops.fused_linear(x, w, epilogue="residual_add", out=res), w_o)
+run("qkv      K=896 N=1152 folded-norm + bias + RoPE + KV store, packed x", (H + 2 * KVH) * D // 32, lambda w: ops.fused_linear(xp, w, x_packed_rows=M, bias=b_qkv, norm_folded=True, norm_eps=1e-6, epilogue="rope_store", rope=rope), w_qkv)
 run("o_proj   same, packed x", HID // 16, lambda w: ops.fused_linear(xp, w, x_packed_rows=M, epilogue="residual_add", out=res), w_o)
