@@ -240,9 +240,23 @@ typedef struct nvh_linear_desc {
                                        kernel leaves its tickets zero); needed when k > 1024: K is then split over
                                        workgroups and the last-arriving one sums the partials in a fixed order */
     size_t workspace_bytes;
+    /* greedy candidates (NONE epilogue, k <= 1024): every workgroup also writes, per row, the largest bf16 output among its
+       columns and that column's index to candidate_val / candidate_idx [workgroup * candidate_stride + row]
+       (nvh_linear_small_m_candidate_groups() workgroups; ties -> lowest column).  With candidates `out` may be NULL: the LM
+       head + arg-max of a greedy decode step then never materialises the logits (layers/embed_head.py:66 +
+       layers/sampler.py at temperature 0); finish with nvh_greedy_advance_candidates. */
+    float* candidate_val;
+    int32_t* candidate_idx;
+    int64_t candidate_stride;
 } nvh_linear_desc;
 int nvh_linear_small_m_ex(const nvh_linear_desc* desc, int dtype, void* stream);
 size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue);
+int nvh_linear_small_m_candidate_groups(int n, int k);      /* candidate records per row of a NONE launch; 0 = unsupported shape */
+/* nvh_greedy_advance on candidate records instead of logits: token = column of the best candidate of each row */
+int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
+                                  int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                                  const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                                  int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, void* stream);
 /* offset (in elements) of activation element (row, col) of an [m, cols] matrix in fragment order */
 int64_t nvh_pack_index(int row, int col, int cols);
 

@@ -338,7 +338,12 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     if (!d) { set_error("linear_small_m_ex: null descriptor"); return NVH_E_NULL; }
     if (d->m == 0) return 0;
     if (dtype != NVH_BF16) { set_error("linear_small_m_ex: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
-    const bool out_optional = d->out_packed && (d->epilogue == NVH_EPI_NONE || d->epilogue == NVH_EPI_SILU_MUL);
+    const bool out_optional = (d->out_packed && (d->epilogue == NVH_EPI_NONE || d->epilogue == NVH_EPI_SILU_MUL)) ||
+                              (d->candidate_val && d->epilogue == NVH_EPI_NONE);
+    if ((d->candidate_val != nullptr) != (d->candidate_idx != nullptr) || (d->candidate_val && d->candidate_stride < d->m)) {
+        set_error("linear_small_m_ex: candidate_val / candidate_idx come together, candidate_stride >= m");
+        return NVH_E_NULL;
+    }
     if ((!d->out && !out_optional) || !d->x || !d->w) { set_error("linear_small_m_ex: null pointer"); return NVH_E_NULL; }
     if (d->m < 0 || d->m > 64 || d->n <= 0 || d->k <= 0 || d->k % 64 || d->n % 16) {
         set_error("linear_small_m_ex: m=%d (<=64) n=%d (%%16) k=%d (%%64)", d->m, d->n, d->k);
@@ -379,16 +384,32 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     a.stamps = g_stamps;
     a.x_packed = d->x_packed; a.out_packed = (uint16_t*)d->out_packed; a.ws_raw = d->workspace; a.ws_bytes = d->workspace_bytes;
     a.ws = nullptr; a.counters = nullptr; a.ksplit = 1; a.tiles = 0;
+    a.cand_val = d->candidate_val; a.cand_idx = d->candidate_idx; a.cand_stride = d->candidate_stride;
     const int rc = launch_linear_stream(a, (hipStream_t)stream);
     if (rc != -100) return rc;
-    if (d->x_packed || d->out_packed) {
-        set_error("linear_small_m_ex: packed activations need the streaming kernel (k %% 64 == 0, no exact-norm prologue, workspace when k > 1024)");
+    if (d->x_packed || d->out_packed || d->candidate_val) {
+        set_error("linear_small_m_ex: packed activations / candidates need the streaming kernel (k %% 64 == 0, no exact-norm prologue, workspace when k > 1024)");
         return NVH_E_SHAPE;
     }
     return launch_linear_small_m(a, (hipStream_t)stream);
 }
 
 size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue) { return linear_stream_workspace_bytes(m, n, k, epilogue); }
+int nvh_linear_small_m_candidate_groups(int n, int k) { return linear_stream_candidate_groups(n, k); }
+
+int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
+                                  int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                                  const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                                  int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, void* stream) {
+    if (n_rows == 0) return 0;
+    if (!candidate_val || !candidate_idx || !input_ids || !positions || !context_lens || !slot_mapping || !block_tables || !tokens_log || !row_steps) {
+        set_error("greedy_advance_candidates: null pointer");
+        return NVH_E_NULL;
+    }
+    if (n_rows < 0 || groups <= 0 || candidate_stride < n_rows || block_size <= 0 || log_row_stride < n_rows) { set_error("greedy_advance_candidates: bad shape"); return NVH_E_SHAPE; }
+    AdvanceArgs adv{input_ids, positions, context_lens, slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps};
+    return launch_argmax_candidates(candidate_val, candidate_idx, groups, candidate_stride, n_rows, adv, (hipStream_t)stream);
+}
 int64_t nvh_pack_index(int row, int col, int cols) { return pack_index(row, col, cols); }
 
 }  // extern "C"

@@ -67,6 +67,9 @@ struct AdvanceArgs {             // all null: plain argmax
     int64_t* row_steps;          // [rows] tokens generated so far per row (log row index)
 };
 int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, const AdvanceArgs& adv, hipStream_t stream);
+int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows,
+                             const AdvanceArgs& adv, hipStream_t stream);
+int linear_stream_candidate_groups(int n, int k);   // workgroups (= candidate records per row) of a NONE launch, 0 if unsupported
 
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_RESADD = 2, EPI_ROPE = 3 };   // == NVH_EPI_* in nvh_attn.h
 
@@ -98,6 +101,9 @@ struct LinearArgs {
     unsigned* counters;          // [tiles] arrival tickets, zero before the launch, left zero by it
     int ksplit;                  // workgroups sharing one tile's K range (>= 1)
     int tiles;                   // weight row tiles (16 rows, or 16 + 16 partner rows for SILU / ROPE)
+    float* cand_val;             // NONE only, nullable: greedy candidates instead of (or besides) the outputs: every workgroup
+    int32_t* cand_idx;           // writes, per row, the largest bf16 output of its columns and that column's index:
+    int64_t cand_stride;         // cand_*[workgroup * cand_stride + row]; ties -> lowest column (lm_head + argmax in one pass)
 };
 int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
 int launch_linear_stream(const LinearArgs& a, hipStream_t stream);   // linear_stream.hip; returns -100 when the shape is not its own

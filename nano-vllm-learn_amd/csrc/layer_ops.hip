@@ -104,6 +104,50 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
 
 // Greedy sampling: argmax over each row of bf16 logits (nanovllm/layers/sampler.py at temperature 0 reduces to this).
 // One 1024-thread workgroup per row streams the row with 16-byte loads; ties resolve to the lowest index.
+// scheduler.postprocess (append the token) + prepare_decode for the NEXT step (engine/model_runner.py:244-269), on the device:
+// the row's workgroup owns the row's metadata, so there is nothing to synchronise
+__device__ __forceinline__ void advance_row(const AdvanceArgs& adv, int row, int token) {
+    const int ctx = adv.context_lens[row];
+    if (ctx > 0) {                                             // padding rows (ctx 0, slot -1) stay as they are
+        adv.tokens_log[adv.row_steps[row] * adv.log_stride + row] = token;
+        adv.row_steps[row] += 1;
+        adv.input_ids[row] = token;
+        adv.positions[row] += 1;
+        adv.context_lens[row] = ctx + 1;
+        const int last = ctx;                                  // index of the token the next step stores: new_ctx - 1
+        adv.slot_mapping[row] = adv.block_tables[row * adv.bt_stride + last / adv.block_size] * adv.block_size + last % adv.block_size;
+    }
+}
+
+// Final step of the fused lm_head + argmax: per row, the best of `groups` candidates (value desc, column asc), then the
+// advance bookkeeping.  One 256-thread workgroup per row.
+__global__ __launch_bounds__(256) void argmax_candidates_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
+                                                                 int groups, int64_t cand_stride, const AdvanceArgs adv) {
+    __shared__ float lds_v[4];
+    __shared__ int lds_i[4];
+    const int row = blockIdx.x;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int gi = threadIdx.x; gi < groups; gi += 256) {
+        const float v = cand_val[(int64_t)gi * cand_stride + row];
+        const int i = cand_idx[(int64_t)gi * cand_stride + row];
+        if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { lds_v[threadIdx.x >> 6] = best; lds_i[threadIdx.x >> 6] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+        advance_row(adv, row, bidx);
+    }
+}
+
 __global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__ out, const uint16_t* __restrict__ x, int n, int64_t stride,
                                                             const AdvanceArgs adv) {
     __shared__ float lds_v[16];
@@ -139,21 +183,7 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__
         for (int w = 1; w < 16; ++w)
             if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
         if (out) out[blockIdx.x] = bidx;
-        if (adv.input_ids) {
-            // scheduler.postprocess (append the token) + prepare_decode for the NEXT step (engine/model_runner.py:244-269),
-            // on the device: this row's workgroup owns this row's metadata, so there is nothing to synchronise
-            const int row = blockIdx.x;
-            const int ctx = adv.context_lens[row];
-            if (ctx > 0) {                                         // padding rows (ctx 0, slot -1) stay as they are
-                adv.tokens_log[adv.row_steps[row] * adv.log_stride + row] = bidx;
-                adv.row_steps[row] += 1;
-                adv.input_ids[row] = bidx;
-                adv.positions[row] += 1;
-                adv.context_lens[row] = ctx + 1;
-                const int last = ctx;                              // index of the token the next step stores: new_ctx - 1
-                adv.slot_mapping[row] = adv.block_tables[row * adv.bt_stride + last / adv.block_size] * adv.block_size + last % adv.block_size;
-            }
-        }
+        if (adv.input_ids) advance_row(adv, blockIdx.x, bidx);
     }
 }
 
@@ -163,6 +193,13 @@ int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t s
     if (n_rows == 0) return 0;
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_rows), dim3(1024), 0, stream, out, (const uint16_t*)x, n, stride, adv);
     return check_launch("argmax_rows");
+}
+
+int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows,
+                             const AdvanceArgs& adv, hipStream_t stream) {
+    if (n_rows == 0) return 0;
+    hipLaunchKernelGGL(argmax_candidates_kernel, dim3(n_rows), dim3(256), 0, stream, cand_val, cand_idx, groups, cand_stride, adv);
+    return check_launch("argmax_candidates");
 }
 
 int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, float eps, int n_rows, int hidden,

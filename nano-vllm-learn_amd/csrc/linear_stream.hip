@@ -195,6 +195,10 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
 #pragma unroll
     for (int m = 0; m < MT; ++m) ss2[m] = 0.f;
     bool ss_done = false;
+    float best_v[MT];                                          // greedy candidates (NONE + cand_val): running max per owned element slot
+    int best_i[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) { best_v[j] = -INFINITY; best_i[j] = 0x7fffffff; }
 
     for (int tile = tile_first, buf = 0; tile < tile_end; ++tile, buf ^= (NBUF - 1)) {
         if (MULTI && tile + 1 < tile_end) {
@@ -389,9 +393,36 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
                 const __bf16 o = (__bf16)(y[0] + (a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f));
                 if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
                 if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.N)] = __builtin_bit_cast(uint16_t, o);
+                if (a.cand_val && (float)o > best_v[j]) {                  // tiles ascend: a strict > keeps the lowest column
+                    best_v[j] = (float)o;
+                    best_i[j] = n0 + c;
+                }
             }
         }
         if (MULTI) __syncthreads();                                   // reduction tiles read before the next-but-one DMA lands on them
+    }
+    if constexpr (EPI == EPI_NONE) {
+        if (a.cand_val) {
+            // element slot j of thread tid is (row = 16*mt + 4*(l>>4) + r, column l&15) with l = (v>>2)&63, v = tid + 256 j: the 16
+            // columns of one row sit in one wave at lane stride 4 -> fold lanes 4, 8, 16, 32 apart (value desc, column asc)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                float bv = best_v[j];
+                int bi = best_i[j];
+#pragma unroll
+                for (int off = 4; off < 64; off <<= 1) {
+                    const float ov = __shfl_xor(bv, off, 64);
+                    const int oi = __shfl_xor(bi, off, 64);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                const int v = tid + 256 * j, l = (v >> 2) & 63;
+                const int row = 16 * (v >> 8) + 4 * (l >> 4) + (v & 3);
+                if ((l & 15) == 0 && row < a.M) {
+                    a.cand_val[(int64_t)blockIdx.x * a.cand_stride + row] = bv;
+                    a.cand_idx[(int64_t)blockIdx.x * a.cand_stride + row] = bi;
+                }
+            }
+        }
     }
     LS_STAMP(6);
 }
@@ -434,6 +465,12 @@ int tiles_of(int n, int inter, int h, int kvh, int hd, int epi) {
 
 }  // namespace
 
+int linear_stream_candidate_groups(int n, int k) {
+    if (k % 64 != 0 || k / 64 > SW * PMAX || n % 16 != 0) return 0;    // one workgroup must see the whole K range
+    const int tiles = n / 16;
+    return tiles > 1024 ? 512 : tiles;
+}
+
 // counters [tiles] (rounded to 256 B) then partial records [tiles][ksplit][NB*MT*256 + MT*16] fp32; 0 when K needs no split
 size_t linear_stream_workspace_bytes(int m, int n, int k, int epi) {
     const int pieces = k / 64, ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);
@@ -448,6 +485,7 @@ int launch_linear_stream(const LinearArgs& a_in, hipStream_t stream) {
     LinearArgs a = a_in;
     if (a.M == 0) return 0;
     if (a.norm_mode == 1 || a.K % 64 != 0 || a.M > 64) return -100;
+    if (a.cand_val && (a.epi != EPI_NONE || !a.cand_idx || linear_stream_candidate_groups(a.N, a.K) == 0)) return -100;
     a.tiles = tiles_of(a.N, a.inter, a.h, a.kvh, a.hd, a.epi);
     const int pieces = a.K / 64;
     a.ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);

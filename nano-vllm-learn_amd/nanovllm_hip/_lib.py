@@ -23,7 +23,8 @@ class LinearDesc(ctypes.Structure):
                 ("positions", ctypes.c_void_p), ("cos_sin", ctypes.c_void_p), ("k_cache", ctypes.c_void_p), ("v_cache", ctypes.c_void_p),
                 ("slot_mapping", ctypes.c_void_p), ("h", ctypes.c_int32), ("kvh", ctypes.c_int32), ("hd", ctypes.c_int32),
                 ("norm_folded", ctypes.c_int32), ("x_packed", ctypes.c_int32), ("out_packed", ctypes.c_void_p),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
+                ("candidate_val", ctypes.c_void_p), ("candidate_idx", ctypes.c_void_p), ("candidate_stride", ctypes.c_int64)]
 
 
 EPI_NONE, EPI_SILU_MUL, EPI_RESIDUAL_ADD, EPI_ROPE_STORE = 0, 1, 2, 3
@@ -58,6 +59,10 @@ _SIGS = {
     "nvh_linear_small_m_ex": (ctypes.c_int, [ctypes.POINTER(LinearDesc), ctypes.c_int, ctypes.c_void_p]),
     "nvh_linear_small_m_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "nvh_pack_index": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "nvh_linear_small_m_candidate_groups": (ctypes.c_int, [ctypes.c_int] * 2),
+    "nvh_greedy_advance_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int] +
+                                      [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                                                ctypes.c_void_p, ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

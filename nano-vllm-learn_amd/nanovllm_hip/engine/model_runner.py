@@ -215,6 +215,12 @@ class DecodeSession:
     def _step(self):
         set_context(False, slot_mapping=self.slot_mapping, context_lens=self.context_lens, block_tables=self.block_tables)
         hidden = self.runner.model(self.input_ids, self.positions)
+        cand = self.runner.model.greedy_candidates(hidden)     # LM head + arg-max candidates in one launch (fused decode path)
+        if cand is not None:
+            ops.greedy_advance_candidates(cand[0], cand[1], cand[2], self.batch, self.input_ids, self.positions, self.context_lens,
+                                          self.slot_mapping, self.block_tables, self.runner.block_size, self.tokens, self.row_steps)
+            reset_context()
+            return
         logits = self.runner.model.compute_logits(hidden)
         if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.stride(0) % 8 == 0:
             # sampling + postprocess + next step's prepare_decode in ONE launch (nvh_greedy_advance)

@@ -350,6 +350,28 @@ class QwenForCausalLM(nn.Module):
                                     norm_eps=self.norm.eps)
         return linear(hidden_states, w)
 
+    def greedy_candidates(self, hidden_states):
+        """Fused decode path only: LM head + per-workgroup arg-max candidates in one launch, logits never written.  Returns
+        (val [groups, stride] float32, idx int32, groups) for ops.greedy_advance_candidates, or None when this path does not
+        apply (then use compute_logits)."""
+        packed = getattr(self, "_pending_final_norm", None)
+        if packed is None or _tp()[1] != 1:
+            return None
+        from .. import ops
+        head = self._folded_weights()["head"]
+        n, k = head.shape
+        groups = ops.linear_candidate_groups(n, k)
+        if groups <= 0:
+            return None
+        m = hidden_states.shape[0]
+        b = self._decode_buffers(m, hidden_states.device)
+        if "cand" not in b:
+            b["cand"] = (torch.empty((groups, 64), dtype=torch.float32, device=hidden_states.device),
+                         torch.empty((groups, 64), dtype=torch.int32, device=hidden_states.device))
+        self._pending_final_norm = None
+        ops.fused_linear(packed, head, x_packed_rows=m, norm_folded=True, norm_eps=self.norm.eps, candidates=b["cand"], want_out=False)
+        return b["cand"][0], b["cand"][1], groups
+
     @torch.no_grad()
     def init_random(self, seed=0):
         """Deterministic N(0, 0.02) weights; every rank draws the full tensors and keeps its shard so that

@@ -306,13 +306,16 @@ _EPI_CODES = {"none": _lib.EPI_NONE, "silu_mul": _lib.EPI_SILU_MUL, "residual_ad
 
 
 def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_folded=False, epilogue="none", out=None, rope=None,
-                 x_packed_rows=None, out_packed=None, workspace=None, want_out=True):
+                 x_packed_rows=None, out_packed=None, workspace=None, want_out=True, candidates=None):
     """nvh_linear_small_m_ex: x [M<=64, K] . weight[N, K]^T with an optional RMSNorm prologue and one of the epilogues
     "none" (+bias) | "silu_mul" | "residual_add" (out = the residual stream, updated in place) | "rope_store"
     (rope = dict(positions, cos_sin, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads, head_dim); returns q [M, H*D]).
     Streaming form: x_packed_rows = M when `x` is a flat fragment-order buffer (pack_rows); out_packed = a flat bf16 buffer
     that receives the result in fragment order as well; workspace = a ZERO-FILLED uint8 buffer of linear_workspace_bytes()
-    (needed for K > 1024); want_out=False skips the row-major output when out_packed is given ("none" / "silu_mul")."""
+    (needed for K > 1024); want_out=False skips the row-major output when out_packed is given ("none" / "silu_mul");
+    candidates = (val float32 [groups, stride], idx int32 [groups, stride]) with groups = linear_candidate_groups(n, k):
+    per workgroup and row the best bf16 output and its column ("none" only) — with want_out=False the outputs themselves are
+    never written (LM head + greedy arg-max in one pass; finish with greedy_advance_candidates)."""
     _require_gpu_bf16(x=x, weight=weight)
     n, k = weight.shape
     if x_packed_rows is not None:
@@ -359,13 +362,36 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
     if workspace is not None:
         assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.is_contiguous()
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel()
-    if out is None and (want_out or out_packed is None):
+    if candidates is not None:
+        cv, ci = candidates
+        assert epilogue == "none" and cv.dtype == torch.float32 and ci.dtype == torch.int32 and cv.is_cuda and ci.is_cuda
+        assert cv.shape == ci.shape and cv.dim() == 2 and cv.is_contiguous() and ci.is_contiguous()
+        assert cv.shape[0] >= linear_candidate_groups(n, k) > 0 and cv.shape[1] >= m
+        d.candidate_val, d.candidate_idx, d.candidate_stride = cv.data_ptr(), ci.data_ptr(), cv.stride(0)
+    if out is None and (want_out or (out_packed is None and candidates is None)):
         out = torch.empty((m, cols), dtype=torch.bfloat16, device=x.device)
     if out is not None:
         d.out, d.out_row_stride = out.data_ptr(), out.stride(0)
     rc = _lib.load().nvh_linear_small_m_ex(ctypes.byref(d), NVH_BF16, _stream())
     _lib.check(rc, "nvh_linear_small_m_ex")
     return out
+
+
+def linear_candidate_groups(n, k) -> int:
+    return int(_lib.load().nvh_linear_small_m_candidate_groups(n, k))
+
+
+def greedy_advance_candidates(cand_val, cand_idx, groups, n_rows, input_ids, positions, context_lens, slot_mapping, block_tables, block_size,
+                              tokens_log, row_steps):
+    """greedy_advance on the candidate records of fused_linear(candidates=...) instead of logits."""
+    _require_i32(context_lens=context_lens, slot_mapping=slot_mapping, block_tables=block_tables)
+    for t in (input_ids, positions, tokens_log, row_steps):
+        assert t.dtype == torch.int64 and t.is_cuda
+    rc = _lib.load().nvh_greedy_advance_candidates(cand_val.data_ptr(), cand_idx.data_ptr(), groups, cand_val.stride(0), n_rows,
+                                                   input_ids.data_ptr(), positions.data_ptr(), context_lens.data_ptr(), slot_mapping.data_ptr(),
+                                                   block_tables.data_ptr(), block_tables.stride(0), block_size, tokens_log.data_ptr(),
+                                                   tokens_log.stride(0), row_steps.data_ptr(), _stream())
+    _lib.check(rc, "nvh_greedy_advance_candidates")
 
 
 def argmax_rows(logits):

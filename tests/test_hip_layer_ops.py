@@ -344,3 +344,47 @@ def test_stream_linear_packed_activations(m, n, k, epi):
         assert ops.fused_linear(ops.pack_rows(x), w, x_packed_rows=m, out_packed=packed2, want_out=False, **kw) is None
         torch.cuda.synchronize()
         assert torch.equal(packed2, packed)
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 151936, 896), (5, 2048, 896), (17, 32000, 1024)])
+def test_stream_linear_greedy_candidates(m, n, k):
+    """LM head + arg-max candidates in one launch: reducing the candidate records gives exactly the arg-max (lowest index on
+    ties) of the bf16 logits the same kernel writes, in both grid forms (one tile per workgroup / multi-tile workgroups)."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(n + k + m)
+    x = torch.randn(m, k, generator=g).bfloat16().cuda()
+    w = (torch.randn(n, k, generator=g) * 0.05).bfloat16().cuda()
+    w[n - 7] = w[11]                                           # duplicate rows: exact ties between columns 11 and n-7
+    w[n // 2] = w[3]
+    groups = ops.linear_candidate_groups(n, k)
+    assert groups > 0
+    cv = torch.full((groups, 64), float("nan"), dtype=torch.float32, device="cuda")
+    ci = torch.full((groups, 64), -1, dtype=torch.int32, device="cuda")
+    logits = ops.fused_linear(x, w, norm_folded=True, norm_eps=1e-6, candidates=(cv, ci))
+    torch.cuda.synchronize()
+    ref = torch.stack([ops.argmax_rows(logits)]).squeeze(0).cpu()
+    vals = cv[:, :m].cpu()
+    idxs = ci[:, :m].cpu().long()
+    for r in range(m):
+        best = vals[:, r].max()
+        cand = idxs[:, r][vals[:, r] == best].min()
+        assert int(cand) == int(ref[r]) and float(best) == float(logits[r, cand])
+    # candidates-only launch (no logits) + the advance kernel on a fake session state
+    cv2, ci2 = torch.zeros_like(cv), torch.zeros_like(ci)
+    assert ops.fused_linear(ops.pack_rows(x), w, x_packed_rows=m, norm_folded=True, norm_eps=1e-6, candidates=(cv2, ci2), want_out=False) is None
+    bs = 256
+    ctx = torch.randint(1, 500, (m,), generator=g).int()
+    ctx[0] = 0                                                 # a padding row: untouched
+    bt = torch.arange(m * 2, dtype=torch.int32).view(m, 2).cuda()
+    ids = torch.zeros(m, dtype=torch.int64, device="cuda")
+    pos = ctx.long().cuda()
+    ctxd, slots = ctx.cuda(), torch.full((m,), -1, dtype=torch.int32, device="cuda")
+    log = torch.zeros(4, m, dtype=torch.int64, device="cuda")
+    steps = torch.zeros(m, dtype=torch.int64, device="cuda")
+    ops.greedy_advance_candidates(cv2, ci2, groups, m, ids, pos, ctxd, slots, bt, bs, log, steps)
+    torch.cuda.synchronize()
+    live = ctx > 0
+    assert torch.equal(ids.cpu()[live], ref[live]) and torch.equal(log[0].cpu()[live], ref[live])
+    assert torch.equal(ctxd.cpu()[live], ctx[live] + 1) and int(ctxd[0]) == 0 and int(ids[0]) == 0
+    exp_slot = bt.cpu()[torch.arange(m), (ctx // bs).long()] * bs + ctx % bs
+    assert torch.equal(slots.cpu()[live], exp_slot[live].int())
