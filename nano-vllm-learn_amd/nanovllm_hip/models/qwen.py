@@ -300,7 +300,10 @@ class QwenForCausalLM(nn.Module):
         if key not in bufs:
             cfg, rows = self.cfg, ((m + 15) // 16) * 16
             inter = self.layers[0].mlp.down_proj.weight.shape[1]
-            need = max(ops.linear_workspace_bytes(m, cfg.hidden_size, inter, "residual_add"),
+            head = self.embed_tokens.weight if cfg.tie_word_embeddings else self.lm_head.weight
+            need = max(ops.linear_workspace_bytes(m, head.shape[0], cfg.hidden_size, "none"),
+                       ops.linear_workspace_bytes(m, cfg.hidden_size, cfg.hidden_size, "residual_add"),
+                       ops.linear_workspace_bytes(m, cfg.hidden_size, inter, "residual_add"),
                        ops.linear_workspace_bytes(m, self.layers[0].self_attn.qkv_proj.weight.shape[0], cfg.hidden_size, "rope_store"),
                        ops.linear_workspace_bytes(m, 2 * inter, cfg.hidden_size, "silu_mul"), 16)
             bufs[key] = dict(resid_p=torch.zeros(rows * cfg.hidden_size, dtype=torch.bfloat16, device=device),
@@ -346,8 +349,9 @@ class QwenForCausalLM(nn.Module):
         if packed is not None:                                        # fused decode path: final RMSNorm in the LM-head launch
             self._pending_final_norm = None
             from .. import ops
-            return ops.fused_linear(packed, self._folded_weights()["head"], x_packed_rows=hidden_states.shape[0], norm_folded=True,
-                                    norm_eps=self.norm.eps)
+            m = hidden_states.shape[0]
+            return ops.fused_linear(packed, self._folded_weights()["head"], x_packed_rows=m, norm_folded=True, norm_eps=self.norm.eps,
+                                    workspace=self._decode_buffers(m, hidden_states.device)["ws"])
         return linear(hidden_states, w)
 
     def greedy_candidates(self, hidden_states):
