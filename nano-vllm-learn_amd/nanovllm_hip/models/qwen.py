@@ -248,12 +248,15 @@ class QwenDecoderLayer(nn.Module):
         return self.mlp(hidden_states), residual
 
 
+FUSED_DECODE = True          # tests flip this to compare the fused decode layer with the plain one
+
+
 def _fused_decode_ok(cfg, x):
-    """The 6-launch decoder layer (nvh_linear_small_m_ex) applies to single-GPU decode batches of at most 64 rows."""
+    """The 5-launch decoder layer (6 with Qwen3's q/k-norm) applies to single-GPU decode batches of at most 64 rows."""
     from ..utils.context import get_context
     ctx = get_context()
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[0] <= 64 and not ctx.is_prefill and ctx.context_lens is not None
-            and ctx.slot_mapping is not None and not cfg.qk_norm and _tp()[1] == 1 and cfg.attn_backend == "hip")
+    return (FUSED_DECODE and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[0] <= 64 and not ctx.is_prefill
+            and ctx.context_lens is not None and ctx.slot_mapping is not None and _tp()[1] == 1 and cfg.attn_backend == "hip")
 
 
 class QwenForCausalLM(nn.Module):
@@ -328,11 +331,20 @@ class QwenForCausalLM(nn.Module):
         for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
             x, xrows = (residual, None) if i == 0 else (resid_p, m)       # layer 0 reads the embedding rows as they are
-            q = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
-                                 norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws,
-                                 rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
-                                           v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
-                                           num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
+            if a.qk_norm:
+                # Qwen3: the per-head q/k RMSNorm needs a whole head in one workgroup, so it cannot ride in the GEMM epilogue:
+                # plain projection, then (q/k-norm -> RoPE -> KV store) as the one nvh_rope_store launch (qwen3.py:108-116)
+                qkv = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
+                                       norm_eps=layer.input_layernorm.eps, epilogue="none", workspace=ws)
+                ops.rope_store(qkv, positions, a.rotary_emb.table(residual.device), a.num_heads, a.num_kv_heads, a.head_dim,
+                               a.attn.k_cache, a.attn.v_cache, ctx.slot_mapping, a.q_norm.weight, a.k_norm.weight, a.q_norm.eps)
+                q = qkv[:, :a.q_size]
+            else:
+                q = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
+                                     norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws,
+                                     rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
+                                               v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
+                                               num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
             a.attn.decode_attend(q, out_packed=attn_p)
             ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
                              workspace=ws)

@@ -388,3 +388,39 @@ def test_stream_linear_greedy_candidates(m, n, k):
     assert torch.equal(ctxd.cpu()[live], ctx[live] + 1) and int(ctxd[0]) == 0 and int(ids[0]) == 0
     exp_slot = bt.cpu()[torch.arange(m), (ctx // bs).long()] * bs + ctx % bs
     assert torch.equal(slots.cpu()[live], exp_slot[live].int())
+
+
+@pytest.mark.parametrize("name", ["Qwen2-0.5B", "Qwen3-0.6B"])
+def test_fused_decode_layer_matches_plain_layer(name):
+    """One decode step of a 2-layer model through the fused layer (norm-folded streaming GEMMs, packed activations, for Qwen3
+    the separate q/k-norm+RoPE+store launch) against the plain layer-by-layer body: same logits up to bf16 rounding of the
+    intermediate activations, same greedy tokens."""
+    from nanovllm_hip.engine.llm_engine import LLMEngine
+    from nanovllm_hip.engine.model_runner import build_decode_meta
+    from nanovllm_hip.engine.sequence import Sequence
+    from nanovllm_hip.models import qwen
+    from nanovllm_hip.models.qwen import model_config
+    from nanovllm_hip.utils.context import reset_context, set_context
+    cfg = model_config(name, num_hidden_layers=2, vocab_size=4096)
+    g = torch.Generator().manual_seed(7)
+    prompts = [torch.randint(0, 4096, (n,), generator=g).tolist() for n in (300, 17, 256, 5, 129)]
+    logits = {}
+    for fused in (True, False):
+        qwen.FUSED_DECODE = fused
+        try:
+            eng = LLMEngine(cfg, num_kvcache_blocks=16, enforce_eager=True, seed=3)
+            seqs = [Sequence(p, max_tokens=4) for p in prompts]
+            eng.prefill(seqs, reserve_tokens=4)
+            r = eng.runner
+            m = build_decode_meta(seqs, r.block_size)
+            with torch.inference_mode():
+                set_context(False, slot_mapping=r._dev(m["slot_mapping"]), context_lens=r._dev(m["context_lens"]), block_tables=r._dev(m["block_tables"]))
+                hidden = r.model(r._dev(m["input_ids"]), r._dev(m["positions"]))
+                logits[fused] = r.model.compute_logits(hidden).float().cpu()
+                reset_context()
+        finally:
+            qwen.FUSED_DECODE = True
+    a, b = logits[True], logits[False]
+    scale = b.abs().max()
+    assert (a - b).abs().max() <= 0.03 * scale
+    assert torch.equal(a.argmax(-1), b.argmax(-1))
