@@ -502,13 +502,18 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //     (sequence, kv head) merges all records (sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
 //     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
 //     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
-template <int D>
-__global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const DecodeArgs a, const int G) {
-    using geo = MGeo<D>;
-    constexpr int LPT = geo::LPT, TPI = geo::TPI, WT = geo::WT, NI = geo::NI, ROWB = geo::ROWB, NT = geo::NT;
-    constexpr int NHALF = geo::NHALF, STEPS = geo::STEPS, DT = geo::DT, QI = geo::QI, IMG = geo::IMG;
-    constexpr int WAVES = MW, SPLIT = geo::SPLIT;
-    constexpr int WAVE_LDS = 2 * geo::WAVE_BYTES;             // two (K, V) image pairs per wave
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const DecodeArgs a, const int G) {
+    // NW waves share a pass of SPLIT tokens: NW = 4 -> 64-token (D=64) / 32-token (D=128) tiles; NW = 8 (D=64 only) -> 32-token
+    // tiles, two waves per SIMD covering each other's LDS / MFMA latencies, same LDS footprint
+    constexpr int MW = NW;
+    constexpr int SPLIT = MGeo<D>::SPLIT, WT = SPLIT / NW;
+    constexpr int LPT = D / 8, TPI = 64 / LPT, NI = WT / TPI, ROWB = D * 2, NT = WT / 16, NHALF = WT / 32;
+    constexpr int STEPS = D / 32, DT = D / 16, QI = 16 / TPI, IMG = WT * ROWB;
+    constexpr int WAVES = NW;
+    constexpr int WAVE_BYTES = 2 * IMG;                       // K + V image of one tile
+    constexpr int WAVE_LDS = 2 * WAVE_BYTES;                  // two (K, V) image pairs per wave
+    static_assert(NHALF >= 1 && NI >= 1, "a wave tile is at least 32 tokens");
     static_assert(16 * D * 4 <= IMG, "merge tile must fit in one K image");
     __shared__ __attribute__((aligned(16))) unsigned char lds[MW * WAVE_LDS + QI * 1024 + MW * 2 * 16 * 4 + 16];
     unsigned char* const lds_q = lds + MW * WAVE_LDS;
@@ -553,7 +558,7 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const Dec
         const int off0 = t0 - (t0 / a.block_size) * a.block_size;
         const int64_t base = ((int64_t)block_id * a.block_size + off0) * row + (int64_t)kh * D;
         const int last = ctx - t0 - 1;                        // rows past the live range repeat the last live row
-        unsigned char* const kimg = lds_w + buf * geo::WAVE_BYTES;
+        unsigned char* const kimg = lds_w + buf * WAVE_BYTES;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int T = i * TPI + dr;
@@ -600,7 +605,7 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_chunked_kernel(const Dec
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
             }
-            const unsigned char* const lds_k = lds_w + buf * geo::WAVE_BYTES;
+            const unsigned char* const lds_k = lds_w + buf * WAVE_BYTES;
             const unsigned char* const lds_v = lds_k + IMG;
             const int n_live = ctx - tok0;
             if (pass == split) {
@@ -887,8 +892,17 @@ int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
 
 template <int D>
 int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
+    // D = 64: 8 waves (two per SIMD, 32-token tiles) measured 8.5 % faster than 4 waves of 64-token tiles (ctx 1536: 11.0 ->
+    // 10.05 us per call); NVH_DECODE_WAVES=4 selects the old shape for A/B.  D = 128 keeps 4 waves (its images are twice as large).
+    static const int waves = [] { const char* e = getenv("NVH_DECODE_WAVES"); return e ? atoi(e) : 8; }();
     dim3 grid(a.kvh * a.batch, a.chunks);
-    hipLaunchKernelGGL((paged_decode_chunked_kernel<D>), grid, dim3(MW * 64), 0, stream, a, g);
+    if constexpr (D == 64) {
+        if (waves == 8) {
+            hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a, g);
+            return check_launch("paged_decode_chunked");
+        }
+    }
+    hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 4>), grid, dim3(4 * 64), 0, stream, a, g);
     return check_launch("paged_decode_chunked");
 }
 

@@ -34,7 +34,8 @@ def main():
     out = torch.empty_like(q)
     nsplit = (nblk * bs + 255) // 256
     ws = torch.zeros(65536 + b * h * nsplit * (d + 2) * 4, dtype=torch.uint8, device="cuda")   # ticket header + partial records
-    stamps = torch.zeros(b * kvh * nsplit * 32, dtype=torch.int64, device="cuda")
+    waves = 8 if d == 64 else 4                                       # waves per workgroup of the chunked kernel
+    stamps = torch.zeros(b * kvh * nsplit * waves * 8, dtype=torch.int64, device="cuda")
     lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     lib.nvh_paged_decode.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     def call(l):
@@ -44,7 +45,7 @@ def main():
     for rep in range(3):
         for l in range(layers): call(l)
     torch.cuda.synchronize()
-    st = stamps.cpu().numpy().reshape(-1, 4, 8).astype(np.float64) * 0.01     # us
+    st = stamps.cpu().numpy().reshape(-1, waves, 8).astype(np.float64) * 0.01     # us
     st = st[st[:, 0, 1] > 0]                                                   # live workgroups only
     t0 = st[:, :, 0].min()
     names = ["start", "scalars+branch", "first loads issued", "first K landed", "first QK+softmax done", "first V landed", "all passes done",
