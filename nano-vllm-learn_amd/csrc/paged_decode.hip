@@ -275,6 +275,12 @@ __device__ __forceinline__ int chunk_swizzle(int T) {
     return LPT == 8 ? ((T >> 1) & 7) : (T & 15);
 }
 
+// V image swizzle of the chunked kernel (see prefill_mfma.hip chunk_swz_v): makes the transposed V reads conflict free
+template <int LPT>
+__device__ __forceinline__ int chunk_swizzle_v(int T) {
+    return LPT == 8 ? (T & 6) : ((2 * T) & 14);
+}
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
         for (int i = 0; i < NI; ++i) {
             const int T = i * TPI + dr;
             const int Tc = T < last ? T : last;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v_cache + base + Tc * row + (dp ^ chunk_swizzle_v<LPT>(T)) * 8),
                                              (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, NVH_DMA_AUX);
         }
     };
@@ -673,9 +679,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
                     p_hi[i] = (__bf16)pv;
                     p_lo[i] = (__bf16)(pv - (float)p_hi[i]);
                 }
-                const int R = 32 * hh + 4 * lg + vq;          // chunk_swizzle(R) == chunk_swizzle(R + 16)
+                const int R = 32 * hh + 4 * lg + vq;          // chunk_swizzle_v(R) == chunk_swizzle_v(R + 16)
                 const uint32_t vrow = lds_offset(lds_v + R * ROWB + (vp & 1) * 8);
-                const int swz = chunk_swizzle<LPT>(R);
+                const int swz = chunk_swizzle_v<LPT>(R);
                 u32x2 vlo[DT], vhi[DT];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {

@@ -84,6 +84,15 @@ __device__ __forceinline__ int chunk_swz(int row) {
     return LPT == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
+// The V image has its own swizzle: its transposed reads (ds_read_b64_tr_b16) bank per 32-lane half, where lanes address rows
+// r and r+2 (128-byte rows) / r and r+1 (256-byte rows) on the same banks; with the K swizzle those pairs land on the same
+// chunk pair (2-way conflict on every V read: a third of all LDS cycles, SQ_LDS_BANK_CONFLICT).  Even XOR values that differ
+// for the 4 (8) rows of a bank class make the 32 lanes hit 32 distinct 8-byte slots.  Rows r, r+16, r+32 share a value.
+template <int LPT>
+__device__ __forceinline__ int chunk_swz_v(int row) {
+    return LPT == 8 ? (row & 6) : ((2 * row) & 14);
+}
+
 template <int D, bool PAGED, int QT>
 __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a) {
     constexpr int BM = 64 * QT;                      // query rows per workgroup (4 waves x QT x 16)
@@ -165,9 +174,8 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
 #pragma unroll
     for (int j = 0; j < NIW; ++j) {
         const int R = (wave * NIW + j) * TPI + dr;
-        const int ch = (dp ^ chunk_swz<LPT>(R)) * 8;
-        koff[j] = (uint32_t)(R * kstride + ch);
-        voff[j] = (uint32_t)(R * vstride + ch);
+        koff[j] = (uint32_t)(R * kstride + (dp ^ chunk_swz<LPT>(R)) * 8);
+        voff[j] = (uint32_t)(R * vstride + (dp ^ chunk_swz_v<LPT>(R)) * 8);
     }
     auto stage = [&](int tile, int buf) {
         unsigned char* kimg = lds + buf * 2 * IMG;
@@ -192,9 +200,8 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
             if (ragged) {
                 const int R = ins * TPI + dr;
                 const int Rc = kv0 + R < sk ? R : sk - 1 - kv0;
-                const int ch = (dp ^ chunk_swz<LPT>(R)) * 8;
-                ko = (uint32_t)(Rc * kstride + ch);
-                vo = (uint32_t)(Rc * vstride + ch);
+                ko = (uint32_t)(Rc * kstride + (dp ^ chunk_swz<LPT>(R)) * 8);
+                vo = (uint32_t)(Rc * vstride + (dp ^ chunk_swz_v<LPT>(R)) * 8);
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko),
                                              (__attribute__((address_space(3))) void*)(kimg + ins * 1024), 16, 0, 0);
@@ -210,8 +217,8 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     const int vq = lq >> 2, vp = lq & 3;
     uint32_t vaddr[DT];
     {
-        const int R0 = 4 * lg + vq;                  // chunk_swz(R0) == chunk_swz(R0 + 16) == chunk_swz(R0 + 32)
-        const int swz = chunk_swz<LPT>(R0);
+        const int R0 = 4 * lg + vq;                  // chunk_swz_v(R0) == chunk_swz_v(R0 + 16) == chunk_swz_v(R0 + 32)
+        const int swz = chunk_swz_v<LPT>(R0);
 #pragma unroll
         for (int t = 0; t < DT; ++t) vaddr[t] = lds_offset(lds + R0 * ROWB + (vp & 1) * 8 + (((2 * t + (vp >> 1)) ^ swz) * 16));
     }
