@@ -17,6 +17,7 @@ from . import _lib
 from ._lib import NVH_BF16, NVH_F32
 
 _workspaces: dict[int, torch.Tensor] = {}
+_retired_workspaces: list[torch.Tensor] = []
 
 
 def _stream():
@@ -82,6 +83,8 @@ def reserve_workspace(device, nbytes: int) -> torch.Tensor:
     if ws is None or ws.numel() < nbytes:
         if ws is not None and torch.cuda.is_current_stream_capturing():
             return torch.zeros(nbytes, dtype=torch.uint8, device=device)   # graph-pool memory, not cached
+        if ws is not None:
+            _retired_workspaces.append(ws)                 # a captured graph may still point at it: never freed
         ws = torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         if not torch.cuda.is_current_stream_capturing():
             _workspaces[idx] = ws
