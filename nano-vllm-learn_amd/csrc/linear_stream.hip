@@ -68,12 +68,15 @@ __device__ __forceinline__ void wait_all_but_pieces(int np) {
         case 1: wait_vm<PER>(); break;
         case 2: wait_vm<2 * PER>(); break;
         case 3: wait_vm<3 * PER>(); break;
-        default: wait_vm<4 * PER>(); break;
+        case 4: wait_vm<4 * PER>(); break;
+        default: wait_vm<5 * PER>(); break;
     }
 }
 
-template <int MT, int EPI, int NORM, bool XPACK, bool MULTI>
+// PM = most pieces one wave may own (4; 5 where it lets a split-K launch fit the 256 CUs with equal workgroups)
+template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4>
 __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs a) {
+    constexpr int PMAX = PM;
     constexpr int NB = (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;           // weight row blocks per tile
     constexpr int NBUF = MULTI ? 2 : 1;
     constexpr int STAGE = NB * PMAX * 2048;                                    // W staging bytes per wave per buffer
@@ -428,15 +431,27 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
 }
 
 template <int MT, int EPI, int NORM, bool XPACK>
-int launch_x(const LinearArgs& a, hipStream_t stream) {
+int launch_x(const LinearArgs& a_in, hipStream_t stream) {
+    LinearArgs a = a_in;
     const bool multi = EPI == EPI_NONE && a.ksplit == 1 && a.tiles > 1024;
     if (multi) {
         if constexpr (EPI == EPI_NONE) {
             hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, a);
         }
-    } else {
-        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
+        return check_launch("linear_stream");
     }
+    if constexpr (EPI == EPI_RESADD) {
+        // Every workgroup streams at about the same rate, so the most loaded CU sets the load phase: prefer a split that
+        // puts at most one (equal) workgroup on each of the 256 CUs.  down_proj of Qwen2-0.5B: 56 tiles x 5 splits = 280
+        // workgroups (24 CUs doubled) with 4 pieces per wave, 56 x 4 = 224 with 5.
+        const int pieces = a.K / 64, ks5 = (pieces + SW * 5 - 1) / (SW * 5);
+        if (a.ksplit > 1 && a.tiles * a.ksplit > 256 && a.tiles * ks5 <= 256) {
+            a.ksplit = ks5;
+            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 5>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
+            return check_launch("linear_stream");
+        }
+    }
+    hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
     return check_launch("linear_stream");
 }
 
