@@ -74,10 +74,14 @@ __device__ __forceinline__ void wait_all_but_pieces(int np) {
 }
 
 // PM = most pieces one wave may own (4; 5 where it lets a split-K launch fit the 256 CUs with equal workgroups)
-template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4>
+// WIDE (SILU only): a tile is 24 gate + 24 up columns held as four 16-row blocks {gate 0-15, gate 16-23, up 0-15, up 16-23}
+// (the half blocks fetch 8 rows; their other 8 MFMA columns are never stored).  4864 / 24 -> 203 equal workgroups on the 256
+// CUs instead of 304 workgroups of 16 + 16 columns, of which 48 CUs carried two.
+template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4, bool WIDE = false>
 __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs a) {
+    static_assert(!WIDE || (EPI == EPI_SILU && !MULTI), "wide tiles: SiLU gate_up, one tile per workgroup");
     constexpr int PMAX = PM;
-    constexpr int NB = (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;           // weight row blocks per tile
+    constexpr int NB = WIDE ? 4 : (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;   // weight row blocks per tile
     constexpr int NBUF = MULTI ? 2 : 1;
     constexpr int STAGE = NB * PMAX * 2048;                                    // W staging bytes per wave per buffer
     constexpr int PSTRIDE = NB * MT * 256 + MT * 16;                           // floats per (tile, split) partial record
@@ -130,9 +134,16 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
+                    for (int hh = 0; hh < (WIDE && (nb & 1) ? 1 : 2); ++hh) {      // WIDE: blocks 1 and 3 are the 8-row halves
                         const int row = 8 * hh + dr;
-                        const uint16_t* src = a.w + (int64_t)((nb == 0 ? n0 : n1) + row) * a.K + (p0 + pi) * 64 + (dp ^ ((row >> 1) & 7)) * 8;
+                        int wrow;                                    // weight row (= output column) this lane fetches
+                        if constexpr (WIDE) {
+                            wrow = (nb >> 1) * a.inter + 24 * tile + 16 * (nb & 1) + row;
+                            wrow = wrow < a.N ? wrow : a.N - 1;      // the last tile's half blocks run past the matrix: clamped, unused
+                        } else {
+                            wrow = (nb == 0 ? n0 : n1) + row;
+                        }
+                        const uint16_t* src = a.w + (int64_t)wrow * a.K + (p0 + pi) * 64 + (dp ^ ((row >> 1) & 7)) * 8;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                          (__attribute__((address_space(3))) void*)(stage + ((pi * NB + nb) * 2 + hh) * 1024), 16, 0, NVH_DMA_AUX);
                     }
@@ -351,7 +362,17 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
                 for (int nb = 0; nb < NB; ++nb) y[nb] *= inv_row;
             }
             __bf16* const out = reinterpret_cast<__bf16*>(a.out);
-            if constexpr (EPI == EPI_SILU) {
+            if constexpr (EPI == EPI_SILU && WIDE) {
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {                           // full block (16 columns), half block (8 columns)
+                    const int col = 24 * tile + 16 * hb + c;
+                    if ((hb == 1 && c >= 8) || col >= a.inter) continue;
+                    const float g = (float)(__bf16)y[hb], u = (float)(__bf16)y[2 + hb];
+                    const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
+                    if (out) out[(int64_t)row * a.out_stride + col] = o;
+                    if (a.out_packed) a.out_packed[pack_index(row, col, a.inter)] = __builtin_bit_cast(uint16_t, o);
+                }
+            } else if constexpr (EPI == EPI_SILU) {
                 const float g = (float)(__bf16)y[0], u = (float)(__bf16)y[1];          // the projection output is bf16 in the reference
                 const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
                 if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
@@ -439,6 +460,14 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
             hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, a);
         }
         return check_launch("linear_stream");
+    }
+    if constexpr (EPI == EPI_SILU) {
+        const int wide_tiles = (a.inter + 23) / 24;                  // 24 + 24 columns per workgroup
+        if (a.ksplit == 1 && a.tiles > 256 && wide_tiles <= 256 && a.inter % 8 == 0) {
+            a.tiles = wide_tiles;
+            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 4, true>), dim3(a.tiles, 1), dim3(SW * 64), 0, stream, a);
+            return check_launch("linear_stream");
+        }
     }
     if constexpr (EPI == EPI_RESADD) {
         // Every workgroup streams at about the same rate, so the most loaded CU sets the load phase: prefer a split that
