@@ -10,6 +10,8 @@ echo "# config 3: B=64"
 for c in 2049 3072 4096; do timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --batch 64 --ctx $c; done
 echo "# config 4 per-rank shape (Qwen2-7B tp=4: 7/1/128)"
 timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --heads 7 --kv-heads 1 --head-dim 128 --ctx 1536
+echo "# Qwen3-0.6B head shape (16/8/128): 8 kv heads -> 8x the K/V bytes per layer"
+for c in 1025 1536 2048; do timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --heads 16 --kv-heads 8 --head-dim 128 --ctx $c; done
 echo "# prefill S sweep (config 5 family), Qwen2-0.5B heads"
 for s in 128 256 512 1024 2048 4096; do timeout -k 10 100 python3 tools/microbench.py prefill --batch $((16384 / s > 256 ? 256 : 16384 / s)) --seq $s; done
 echo "# prefill, Qwen3-0.6B heads (16/8/128)"
