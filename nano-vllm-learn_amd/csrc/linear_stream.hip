@@ -17,7 +17,12 @@
 //   * the folded-norm row sums use v_dot2_f32_bf16 on the packed pairs; the residual operand of RESADD is fetched while W
 //     is in flight.
 //   * wide N (LM head): a workgroup walks several tiles with x held in registers and the next tile's W DMA in flight
-//     (MULTI), so x is fetched once per workgroup instead of once per tile.
+//     (MULTI), so x is fetched once per workgroup instead of once per tile; with candidate buffers it also keeps the
+//     running arg-max of its columns, so a greedy decode step never writes the logits.
+//   * LAUNCH BALANCE: every workgroup streams at about the same ~45 GB/s whatever it does, so the most loaded CU sets a
+//     launch's load phase.  Launches are therefore shaped to at most 256 EQUAL workgroups where the shape allows: down_proj
+//     takes 5 pieces per wave (PM) so that 56 tiles x 4 splits = 224 (not 280), gate_up uses WIDE tiles of 24 + 24
+//     columns -> 203 workgroups (not 304).  (Fewer, fatter workgroups than that lose: see DESIGN.md section 8.)
 // Hand-off (split-K), fence-free form: the partials are stored write-through (relaxed agent-scope atomic stores = `sc1`
 // stores), every storing wave drains them (s_waitcnt vmcnt(0)), workgroup barrier, lane 0 takes the ticket (relaxed agent
 // atomic add); the workgroup whose add came last reads all partials with `sc1` loads (relaxed agent-scope atomic loads) after
