@@ -84,7 +84,7 @@ def test_linear_small_m(m, n, k, bias):
     assert (err <= 2.0 ** -8 * ref.abs() + 2e-3).all(), err.max()          # one bf16 rounding of the fp32 result (+ summation-order slack)
 
 
-@pytest.mark.parametrize("m,inter,k", [(32, 4864, 896), (5, 608, 896), (64, 1536, 1024)])
+@pytest.mark.parametrize("m,inter,k", [(32, 4864, 896), (5, 608, 896), (64, 1536, 1024), (17, 4864, 896), (64, 4864, 896), (9, 4112, 1024)])
 def test_linear_small_m_silu(m, inter, k):
     """gate_up projection + SiluAndMul in one launch == F.linear -> bf16 -> silu*mul (activation.py:11-14)."""
     from nanovllm_hip import ops
@@ -346,7 +346,7 @@ def test_stream_linear_packed_activations(m, n, k, epi):
         assert torch.equal(packed2, packed)
 
 
-@pytest.mark.parametrize("m,n,k", [(32, 151936, 896), (5, 2048, 896), (17, 32000, 1024)])
+@pytest.mark.parametrize("m,n,k", [(32, 151936, 896), (5, 2048, 896), (17, 32000, 1024), (64, 151936, 896)])
 def test_stream_linear_greedy_candidates(m, n, k):
     """LM head + arg-max candidates in one launch: reducing the candidate records gives exactly the arg-max (lowest index on
     ties) of the bf16 logits the same kernel writes, in both grid forms (one tile per workgroup / multi-tile workgroups)."""
