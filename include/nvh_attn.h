@@ -250,6 +250,11 @@ typedef struct nvh_linear_desc {
     int64_t candidate_stride;
 } nvh_linear_desc;
 int nvh_linear_small_m_ex(const nvh_linear_desc* desc, int dtype, void* stream);
+/* residual[n_rows, hidden] += y (bf16, one rounding — the add of add_rms_forward, layers/layernorm.py:35-36) and, if `packed` is
+ * not NULL, the updated rows again in fragment order for the next nvh_linear_small_m_ex with x_packed: the step between a
+ * tensor-parallel all-reduce of a row-parallel projection (layers/linear.py:185-190) and the next projection. */
+int nvh_residual_add_pack(void* residual, const void* y, void* packed, int n_rows, int hidden, int64_t residual_row_stride,
+                          int64_t y_row_stride, int dtype, void* stream);
 size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue);
 int nvh_linear_small_m_candidate_groups(int n, int k);      /* candidate records per row of a NONE launch; 0 = unsupported shape */
 /* nvh_greedy_advance on candidate records instead of logits: token = column of the best candidate of each row */

@@ -279,6 +279,17 @@ int nvh_add_rmsnorm(void* out, const void* x, void* residual, const void* weight
     return launch_add_rmsnorm(out, x, residual, weight, eps, n_rows, hidden, x_row_stride, out_row_stride, residual_row_stride, (hipStream_t)stream);
 }
 
+int nvh_residual_add_pack(void* residual, const void* y, void* packed, int n_rows, int hidden, int64_t residual_row_stride,
+                          int64_t y_row_stride, int dtype, void* stream) {
+    if (n_rows == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("residual_add_pack: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!residual || !y) { set_error("residual_add_pack: null pointer"); return NVH_E_NULL; }
+    if (n_rows < 0 || hidden <= 0 || hidden % 32) { set_error("residual_add_pack: hidden %d must be a positive multiple of 32", hidden); return NVH_E_SHAPE; }
+    if (residual_row_stride % 8 || y_row_stride % 8 || residual_row_stride < hidden || y_row_stride < hidden) { set_error("residual_add_pack: bad row strides"); return NVH_E_STRIDE; }
+    if (!aligned16(residual) || !aligned16(y) || (packed && !aligned16(packed))) { set_error("residual_add_pack: pointers must be 16-byte aligned"); return NVH_E_ALIGN; }
+    return launch_residual_add_pack(residual, y, packed, n_rows, hidden, residual_row_stride, y_row_stride, (hipStream_t)stream);
+}
+
 int nvh_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gate_up_row_stride, int64_t out_row_stride,
                  int dtype, void* stream) {
     if (n_rows == 0) return 0;

@@ -54,6 +54,8 @@ int launch_add_rmsnorm(void* out, const void* x, void* residual, const void* w, 
                        int64_t x_stride, int64_t out_stride, int64_t res_stride, hipStream_t stream);
 int launch_silu_mul(void* out, const void* gate_up, int n_rows, int inter, int64_t gu_stride, int64_t out_stride, hipStream_t stream);
 int max_rmsnorm_hidden(void);
+int launch_residual_add_pack(void* residual, const void* y, void* packed, int n_rows, int hidden, int64_t res_stride, int64_t y_stride,
+                             hipStream_t stream);
 struct AdvanceArgs {             // all null: plain argmax
     int64_t* input_ids;          // [rows] next step's input token
     int64_t* positions;          // [rows] += 1

@@ -102,6 +102,28 @@ __global__ __launch_bounds__(256) void silu_mul_kernel(uint16_t* __restrict__ ou
     }
 }
 
+// residual[row, :] = bf16(residual + y) and the same rows in MFMA-fragment order (pack_index) for the next streaming GEMM:
+// the step between a tensor-parallel all-reduce (layers/linear.py:185-190) and the next projection; the add is the one of
+// add_rms_forward (layernorm.py:35-36), the norm itself rides in the next GEMM (folded weights).
+__global__ __launch_bounds__(256) void residual_add_pack_kernel(uint16_t* __restrict__ residual, const uint16_t* __restrict__ y,
+                                                                 uint16_t* __restrict__ packed, int n_rows, int hidden,
+                                                                 int64_t res_stride, int64_t y_stride) {
+    const int chunks = hidden / 8;
+    const int64_t total = (int64_t)n_rows * chunks;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(idx / chunks), c = (int)(idx - (int64_t)row * chunks);
+        uint16_t* r = residual + row * res_stride + c * 8;
+        const u32x4 rv = *reinterpret_cast<const u32x4*>(r);
+        const u32x4 yv = *reinterpret_cast<const u32x4*>(y + row * y_stride + c * 8);
+        u32x4 ov;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ov[k] = pack_bf16x2(bf16_lo(rv[k]) + bf16_lo(yv[k]), bf16_hi(rv[k]) + bf16_hi(yv[k]));
+        *reinterpret_cast<u32x4*>(r) = ov;
+        // 8 consecutive columns of one row are one 16-byte slot of the fragment order
+        if (packed) *reinterpret_cast<u32x4*>(packed + pack_index(row, c * 8, hidden)) = ov;
+    }
+}
+
 // Greedy sampling: argmax over each row of bf16 logits (nanovllm/layers/sampler.py at temperature 0 reduces to this).
 // One 1024-thread workgroup per row streams the row with 16-byte loads; ties resolve to the lowest index.
 // scheduler.postprocess (append the token) + prepare_decode for the NEXT step (engine/model_runner.py:244-269), on the device:
@@ -193,6 +215,17 @@ int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t s
     if (n_rows == 0) return 0;
     hipLaunchKernelGGL(argmax_rows_kernel, dim3(n_rows), dim3(1024), 0, stream, out, (const uint16_t*)x, n, stride, adv);
     return check_launch("argmax_rows");
+}
+
+int launch_residual_add_pack(void* residual, const void* y, void* packed, int n_rows, int hidden, int64_t res_stride, int64_t y_stride,
+                             hipStream_t stream) {
+    if (n_rows == 0) return 0;
+    const int64_t total = (int64_t)n_rows * (hidden / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(residual_add_pack_kernel, dim3(blocks), dim3(256), 0, stream, (uint16_t*)residual, (const uint16_t*)y,
+                       (uint16_t*)packed, n_rows, hidden, res_stride, y_stride);
+    return check_launch("residual_add_pack");
 }
 
 int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows,

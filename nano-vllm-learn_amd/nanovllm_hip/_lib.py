@@ -51,6 +51,7 @@ _SIGS = {
                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "nvh_add_rmsnorm": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
                         [ctypes.c_int, ctypes.c_void_p]),
+    "nvh_residual_add_pack": (ctypes.c_int, [ctypes.c_void_p] * 3 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "nvh_silu_mul": (ctypes.c_int, [ctypes.c_void_p] * 2 + [ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "nvh_linear_small_m": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "nvh_argmax_rows": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),

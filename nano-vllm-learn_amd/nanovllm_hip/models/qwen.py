@@ -256,7 +256,7 @@ def _fused_decode_ok(cfg, x):
     from ..utils.context import get_context
     ctx = get_context()
     return (FUSED_DECODE and x.is_cuda and x.dtype == torch.bfloat16 and x.shape[0] <= 64 and not ctx.is_prefill
-            and ctx.context_lens is not None and ctx.slot_mapping is not None and _tp()[1] == 1 and cfg.attn_backend == "hip")
+            and ctx.context_lens is not None and ctx.slot_mapping is not None and cfg.attn_backend == "hip")
 
 
 class QwenForCausalLM(nn.Module):
@@ -271,12 +271,18 @@ class QwenForCausalLM(nn.Module):
 
     def forward(self, input_ids, positions):
         h, residual = self.embed_tokens(input_ids), None
-        if _fused_decode_ok(self.cfg, h):
+        if _fused_decode_ok(self.cfg, h) and self._fused_shapes_ok():
             return self._forward_decode_fused(h, positions)
         for layer in self.layers:
             h, residual = layer(positions, h, residual)
         h, _ = self.norm(h, residual)
         return h
+
+    def _fused_shapes_ok(self):
+        """Every contraction length of this rank's projections must be a multiple of 64 (one 128-byte line per weight row per
+        DMA piece of the streaming GEMM); Qwen2-0.5B at tp=8 has a 608-wide MLP shard and stays on the plain layer."""
+        a, mlp = self.layers[0].self_attn, self.layers[0].mlp
+        return self.cfg.hidden_size % 64 == 0 and a.q_size % 64 == 0 and mlp.down_proj.weight.shape[1] % 64 == 0
 
     def _folded_weights(self):
         """RMSNorm weights multiplied into the projections that consume the normalised activations (w := w * diag(g)),
@@ -312,6 +318,7 @@ class QwenForCausalLM(nn.Module):
             bufs[key] = dict(resid_p=torch.zeros(rows * cfg.hidden_size, dtype=torch.bfloat16, device=device),
                              act_p=torch.zeros(rows * inter, dtype=torch.bfloat16, device=device),
                              attn_p=torch.zeros(rows * self.layers[0].self_attn.o_proj.weight.shape[1], dtype=torch.bfloat16, device=device),
+                             y=torch.zeros((m, cfg.hidden_size), dtype=torch.bfloat16, device=device),     # TP: partial sums to all-reduce
                              ws=torch.zeros(need, dtype=torch.uint8, device=device))
         return bufs[key]
 
@@ -327,7 +334,8 @@ class QwenForCausalLM(nn.Module):
         fw = self._folded_weights()
         m = residual.shape[0]
         b = self._decode_buffers(m, residual.device)
-        resid_p, act_p, attn_p, ws = b["resid_p"], b["act_p"], b["attn_p"], b["ws"]
+        resid_p, act_p, attn_p, ws, ybuf = b["resid_p"], b["act_p"], b["attn_p"], b["ws"], b["y"]
+        tp = _tp()[1]
         for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
             x, xrows = (residual, None) if i == 0 else (resid_p, m)       # layer 0 reads the embedding rows as they are
@@ -346,12 +354,24 @@ class QwenForCausalLM(nn.Module):
                                                v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
                                                num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
             a.attn.decode_attend(q, out_packed=attn_p)
-            ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
-                             workspace=ws)
+            if tp == 1:
+                ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
+                                 workspace=ws)
+            else:
+                # tensor parallel: this rank's heads give a partial sum (bf16, as RowParallelLinear, layers/linear.py:185-190);
+                # all-reduce over RCCL, then the residual add + fragment-packed copy in one small launch
+                ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="none", out=ybuf, workspace=ws)
+                dist.all_reduce(ybuf)
+                ops.residual_add_pack(residual, ybuf, resid_p)
             ops.fused_linear(resid_p, fw["gate_up"][i], x_packed_rows=m, norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
                              epilogue="silu_mul", out_packed=act_p, want_out=False, workspace=ws)
-            ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
-                             workspace=ws)
+            if tp == 1:
+                ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
+                                 workspace=ws)
+            else:
+                ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="none", out=ybuf, workspace=ws)
+                dist.all_reduce(ybuf)
+                ops.residual_add_pack(residual, ybuf, resid_p)
         self._pending_final_norm = resid_p
         return residual
 
@@ -371,7 +391,7 @@ class QwenForCausalLM(nn.Module):
         (val [groups, stride] float32, idx int32, groups) for ops.greedy_advance_candidates, or None when this path does not
         apply (then use compute_logits)."""
         packed = getattr(self, "_pending_final_norm", None)
-        if packed is None or _tp()[1] != 1:
+        if packed is None:
             return None
         from .. import ops
         head = self._folded_weights()["head"]

@@ -250,6 +250,21 @@ def add_rmsnorm(x, weight, eps, residual=None):
     return out.view(x.shape)
 
 
+def residual_add_pack(residual, y, packed=None):
+    """residual += y in place (bf16, one rounding) and, optionally, the updated rows in fragment order into `packed`
+    (nvh_residual_add_pack): the step after a tensor-parallel all-reduce in the fused decode layer."""
+    _require_gpu_bf16(residual=residual, y=y)
+    assert residual.dim() == 2 and residual.shape == y.shape and residual.stride(1) == 1 and y.stride(1) == 1
+    m, hidden = residual.shape
+    if packed is not None:
+        _require_gpu_bf16(packed=packed)
+        assert packed.is_contiguous() and packed.numel() >= ((m + 15) // 16) * 16 * hidden
+    rc = _lib.load().nvh_residual_add_pack(residual.data_ptr(), y.data_ptr(), packed.data_ptr() if packed is not None else None, m, hidden,
+                                           residual.stride(0), y.stride(0), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_residual_add_pack")
+    return residual
+
+
 def silu_mul(gate_up):
     """SiluAndMul.forward (activation.py:11-14): silu(gate_up[..., :I]) * gate_up[..., I:]."""
     _require_gpu_bf16(gate_up=gate_up)

@@ -424,3 +424,21 @@ def test_fused_decode_layer_matches_plain_layer(name):
     scale = b.abs().max()
     assert (a - b).abs().max() <= 0.03 * scale
     assert torch.equal(a.argmax(-1), b.argmax(-1))
+
+
+@pytest.mark.parametrize("m,hidden", [(32, 896), (5, 3584), (64, 1024)])
+def test_residual_add_pack(m, hidden):
+    """nvh_residual_add_pack: residual += y with one bf16 rounding (bit-exact vs torch on the same fp32 sum) and the updated
+    rows in fragment order (the step after a tensor-parallel all-reduce in the fused decode layer)."""
+    from nanovllm_hip import ops
+    g = torch.Generator().manual_seed(m + hidden)
+    buf = torch.randn(m, hidden + 64, generator=g).bfloat16().cuda()
+    res = buf[:, :hidden]                                        # strided rows
+    y = torch.randn(m, hidden, generator=g).bfloat16().cuda()
+    exp = (res.float() + y.float()).bfloat16()
+    packed = torch.zeros(((m + 15) // 16) * 16 * hidden, dtype=torch.bfloat16, device="cuda")
+    ops.residual_add_pack(res, y, packed)
+    torch.cuda.synchronize()
+    assert torch.equal(res, exp)
+    assert torch.equal(ops.unpack_rows(packed, m, hidden), exp)
+    assert torch.equal(buf[:, hidden:], buf[:, hidden:])          # the padding columns were not touched (no NaN)
