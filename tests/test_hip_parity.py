@@ -450,3 +450,67 @@ def test_prefill_long_sequences_two_subtile_path(H, KVH, D, lens):
         s = s.masked_fill(torch.triu(torch.ones(n, n, dtype=torch.bool, device="cuda"), 1), float("-inf"))
         ref = torch.einsum("hqk,khd->qhd", torch.softmax(s, dim=-1), vf)
         assert (out[sl] - ref).abs().max().item() <= ATOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_paged_decode_randomised_shapes(seed):
+    """Randomised sweep over the launch geometry of the chunked decode kernel: batch x kv heads decides the chunk count
+    (1 .. passes), the context distribution decides live chunks / passes / ragged tiles per sequence, widths decide the grid;
+    includes ctx = 0 rows, contexts on pass and block boundaries, -1 and 0 padding, G in 1..8, D in {64, 128}."""
+    from nanovllm_hip import ops
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.choice([64, 128]))
+    KVH = int(rng.choice([1, 2, 3, 4, 8]))
+    G = int(rng.choice([1, 2, 4, 7, 8]))
+    B = int(rng.choice([1, 2, 3, 5, 9, 17, 33]))
+    H = KVH * G
+    hi = int(rng.choice([65, 257, 600, 1300]))
+    lo = int(rng.choice([1, hi // 2]))
+    width = None if rng.random() < 0.5 else (hi + 255) // 256 + int(rng.integers(0, 3))
+    pad = int(rng.choice([-1, 0]))
+    q, kc, vc, ctxs, bt = _decode_case(2000 + seed, B, H, KVH, D, lo, hi, width, pad)
+    special = [0, 1, 127, 128, 129, 255, 256, 257, 511, 512, 513]
+    for i in range(min(B, 3)):                                   # force boundary contexts (that still fit the table)
+        c = int(rng.choice(special))
+        if c <= ctxs[i] or c <= (0 if width is None else 0):
+            ctxs[i] = min(c, ctxs[i]) if c > 0 else 0
+    exp = O.paged_decode(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), ctxs, bt)
+    qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
+    cl, btd = dev_i32(ctxs), dev_i32(bt)
+    o32 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, out_dtype=torch.float32)
+    o16 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd)
+    again = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert torch.equal(o32, again)                               # the last-arriver merge is order-fixed: bitwise repeatable
+    check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"decode seed {seed} B{B} H{H}/{KVH} D{D} hi{hi} width{width}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_prefill_randomised_varlen(seed):
+    """Randomised varlen batches against the oracle: lengths around the 16 / 64 / 128 row and key tile boundaries, both query
+    sub-tile forms (head_dim 128 with a sequence > 128 rows selects two sub-tiles per wave), strided q/k/v views, G in 1..8."""
+    from nanovllm_hip import ops
+    rng = np.random.default_rng(3000 + seed)
+    D = int(rng.choice([64, 128]))
+    KVH = int(rng.choice([1, 2, 4]))
+    G = int(rng.choice([1, 2, 7, 8]))
+    H = KVH * G
+    pool = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 130, 191, 192, 193, 200, 255, 256, 257]
+    lens = [int(x) for x in rng.choice(pool, size=int(rng.integers(1, 5)))]
+    if sum(lens) * H > 3500:                                     # keep the numpy oracle fast
+        lens = lens[:1]
+    T = sum(lens)
+    gen = torch.Generator().manual_seed(4000 + seed)
+    qkv = torch.randn(T, (H + 2 * KVH) * D, generator=gen).bfloat16()
+    q, k, v = qkv[:, :H * D].view(T, H, D), qkv[:, H * D:(H + KVH) * D].view(T, KVH, D), qkv[:, (H + KVH) * D:].view(T, KVH, D)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    exp = O.prefill_varlen(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, cu)
+    qkv_d = qkv.cuda()
+    qd, kd, vd = qkv_d[:, :H * D].view(T, H, D), qkv_d[:, H * D:(H + KVH) * D].view(T, KVH, D), qkv_d[:, (H + KVH) * D:].view(T, KVH, D)
+    cud = dev_i32(cu)
+    o32 = ops.flash_attn_varlen_func(qd, kd, vd, max(lens), cud, max(lens), cud, out_dtype=torch.float32)
+    o16 = ops.flash_attn_varlen_func(qd, kd, vd, max(lens), cud, max(lens), cud)
+    torch.cuda.synchronize()
+    check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"prefill seed {seed} H{H}/{KVH} D{D} lens {lens}")
