@@ -19,6 +19,9 @@
 //   * wide N (LM head): a workgroup walks several tiles with x held in registers and the next tile's W DMA in flight
 //     (MULTI), so x is fetched once per workgroup instead of once per tile; with candidate buffers it also keeps the
 //     running arg-max of its columns, so a greedy decode step never writes the logits.
+//   * WAVES: 8 per workgroup by default (two per SIMD, half the pieces each): a wave spends most of its life ISSUING (24 DMA +
+//     16 x loads on gate_up ~ 2.8 us at one wave per SIMD) and two waves per SIMD overlap those phases: decode step -4.7 %
+//     (same-box A/B, NVH_GEMM_WAVES=4 restores the old shape).  The multi-tile LM head (two workgroups per CU) stays at 4.
 //   * LAUNCH BALANCE: every workgroup streams at about the same ~45 GB/s whatever it does, so the most loaded CU sets a
 //     launch's load phase.  Launches are therefore shaped to at most 256 EQUAL workgroups where the shape allows: down_proj
 //     takes 5 pieces per wave (PM) so that 56 tiles x 4 splits = 224 (not 280), gate_up uses WIDE tiles of 24 + 24
@@ -28,6 +31,7 @@
 // atomic add); the workgroup whose add came last reads all partials with `sc1` loads (relaxed agent-scope atomic loads) after
 // a workgroup barrier the ticket holder joins.  A release/acquire fence pair here cost 4-5 us per launch (whole-L2
 // write-back + invalidate under 280 workgroups; profiles/r01_gemm_phase_stamps.txt).
+#include <cstdlib>
 #ifndef NVH_DMA_AUX
 #define NVH_DMA_AUX 2        // cache policy of the once-read LDS-DMA streams (weights, K/V): 2 = nt, 0 = default.
                              // nt measured -4.7 % on the decode step, -0.6 us per attention call (same box A/B, round 1)
@@ -82,8 +86,12 @@ __device__ __forceinline__ void wait_all_but_pieces(int np) {
 // WIDE (SILU only): a tile is 24 gate + 24 up columns held as four 16-row blocks {gate 0-15, gate 16-23, up 0-15, up 16-23}
 // (the half blocks fetch 8 rows; their other 8 MFMA columns are never stored).  4864 / 24 -> 203 equal workgroups on the 256
 // CUs instead of 304 workgroups of 16 + 16 columns, of which 48 CUs carried two.
-template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4, bool WIDE = false>
-__global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs a) {
+// NWV = waves per workgroup (4, or 8 with half the pieces per wave: two waves per SIMD overlap each other's issue phases)
+template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4, bool WIDE = false, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArgs a) {
+    constexpr int SW = NWV;                                                    // (shadows the file-scope default of 4)
+    constexpr int TPB = NWV * 64;                                              // threads per workgroup
+    constexpr int EPT = (MT * 256 + TPB - 1) / TPB;                            // output element slots per thread
     static_assert(!WIDE || (EPI == EPI_SILU && !MULTI), "wide tiles: SiLU gate_up, one tile per workgroup");
     constexpr int PMAX = PM;
     constexpr int NB = WIDE ? 4 : (EPI == EPI_SILU || EPI == EPI_ROPE) ? 2 : 1;   // weight row blocks per tile
@@ -180,25 +188,25 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
         }
     }
     // residual operand of RESADD for the elements this thread finishes (value v = tid + 256 j, see below)
-    uint16_t resid[MT];
+    uint16_t resid[EPT];
     if constexpr (EPI == EPI_RESADD && !MULTI) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int v = tid + 256 * j, l = (v >> 2) & 63;
+        for (int j = 0; j < EPT; ++j) {
+            const int v = tid + TPB * j, l = (v >> 2) & 63;
             const int row = 16 * (v >> 8) + 4 * (l >> 4) + (v & 3);
             resid[j] = row < a.M ? reinterpret_cast<const uint16_t*>(a.out)[(int64_t)row * a.out_stride + tile_first * 16 + (l & 15)] : (uint16_t)0;
         }
     }
     // RoPE epilogue operands of the same elements (bias pair, cos, sin, cache slot): two dependent loads deep
     // (positions[row] -> cos_sin row), fetched here so that they travel while W is in flight
-    float rp_b1[MT], rp_b2[MT], rp_co[MT], rp_si[MT];
-    int rp_slot[MT];
+    float rp_b1[EPT], rp_b2[EPT], rp_co[EPT], rp_si[EPT];
+    int rp_slot[EPT];
     if constexpr (EPI == EPI_ROPE && !MULTI) {
         int n0, n1, head, hi0;
         tile_rows(tile_first, n0, n1, head, hi0);
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int v = tid + 256 * j, l = (v >> 2) & 63, c = l & 15;
+        for (int j = 0; j < EPT; ++j) {
+            const int v = tid + TPB * j, l = (v >> 2) & 63, c = l & 15;
             const int row = min(16 * (v >> 8) + 4 * (l >> 4) + (v & 3), a.M - 1);
             rp_b1[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f;
             rp_b2[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n1 + c]) : 0.f;
@@ -214,10 +222,10 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
 #pragma unroll
     for (int m = 0; m < MT; ++m) ss2[m] = 0.f;
     bool ss_done = false;
-    float best_v[MT];                                          // greedy candidates (NONE + cand_val): running max per owned element slot
-    int best_i[MT];
+    float best_v[EPT];                                          // greedy candidates (NONE + cand_val): running max per owned element slot
+    int best_i[EPT];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) { best_v[j] = -INFINITY; best_i[j] = 0x7fffffff; }
+    for (int j = 0; j < EPT; ++j) { best_v[j] = -INFINITY; best_i[j] = 0x7fffffff; }
 
     for (int tile = tile_first, buf = 0; tile < tile_end; ++tile, buf ^= (NBUF - 1)) {
         if (MULTI && tile + 1 < tile_end) {
@@ -281,10 +289,10 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
         int n0, n1, head, hi0;
         tile_rows(tile, n0, n1, head, hi0);
         // value v = (m tile, lane, r): product[16 * mt + 4 * (lane >> 4) + r][column lane & 15 of each weight row block]
-        float s[MT][NB], rowss[MT];
+        float s[EPT][NB], rowss[EPT];
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int v = tid + 256 * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+        for (int j = 0; j < EPT; ++j) {
+            const int v = tid + TPB * j, mt = min(v >> 8, MT - 1), l = (v >> 2) & 63, r = v & 3;   // (slots past MT*256 are never stored)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 s[j][nb] = 0.f;
@@ -301,9 +309,11 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
             // ---- split-K: publish the partial, take a ticket; the last arriver sums all partials in split order
             float* const part = a.ws + ((int64_t)tile * a.ksplit + split) * PSTRIDE;
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
+            for (int j = 0; j < EPT; ++j) {
+                if (tid + TPB * j < MT * 256) {                  // (8 waves, one row tile: the upper half of the threads owns no element)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) st_sc1(part + nb * MT * 256 + tid + 256 * j, s[j][nb]);
+                    for (int nb = 0; nb < NB; ++nb) st_sc1(part + nb * MT * 256 + tid + TPB * j, s[j][nb]);
+                }
             }
             if constexpr (NORM == 2) {
                 if (tid < MT * 16) {
@@ -325,11 +335,12 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
             if (*lds_ticket != (unsigned)a.ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
             const float* const base = a.ws + (int64_t)tile * a.ksplit * PSTRIDE;
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int v = tid + 256 * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+            for (int j = 0; j < EPT; ++j) {
+                const int v = tid + TPB * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) s[j][nb] = 0.f;
                 rowss[j] = 0.f;
+                if (v >= MT * 256) continue;
                 for (int sp0 = 0; sp0 < a.ksplit; sp0 += 8) {
                     float tmp[8][NB + 1];
 #pragma unroll
@@ -353,8 +364,8 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
         if (tile == tile_first) LS_STAMP(5);
         // ---- epilogue
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int v = tid + 256 * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+        for (int j = 0; j < EPT; ++j) {
+            const int v = tid + TPB * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
             const int row = 16 * mt + 4 * (l >> 4) + r;
             if (row >= a.M) continue;
             const int c = l & 15;
@@ -435,7 +446,7 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
             // element slot j of thread tid is (row = 16*mt + 4*(l>>4) + r, column l&15) with l = (v>>2)&63, v = tid + 256 j: the 16
             // columns of one row sit in one wave at lane stride 4 -> fold lanes 4, 8, 16, 32 apart (value desc, column asc)
 #pragma unroll
-            for (int j = 0; j < MT; ++j) {
+            for (int j = 0; j < EPT; ++j) {
                 float bv = best_v[j];
                 int bi = best_i[j];
 #pragma unroll
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(SW * 64) void linear_stream_kernel(const LinearArgs
                     const int oi = __shfl_xor(bi, off, 64);
                     if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                 }
-                const int v = tid + 256 * j, l = (v >> 2) & 63;
+                const int v = tid + TPB * j, l = (v >> 2) & 63;
                 const int row = 16 * (v >> 8) + 4 * (l >> 4) + (v & 3);
                 if ((l & 15) == 0 && row < a.M) {
                     a.cand_val[(int64_t)blockIdx.x * a.cand_stride + row] = bv;
@@ -462,7 +473,9 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
     const bool multi = EPI == EPI_NONE && a.ksplit == 1 && a.tiles > 1024;
     if (multi) {
         if constexpr (EPI == EPI_NONE) {
-            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, a);
+            static const int waves8m = [] { const char* e = getenv("NVH_GEMM_WAVES_MULTI"); return e ? atoi(e) == 8 : 0; }();   // A/B knob
+            if (waves8m) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true, 2, false, 8>), dim3(512), dim3(8 * 64), 0, stream, a);
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, a);
         }
         return check_launch("linear_stream");
     }
@@ -470,7 +483,9 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         const int wide_tiles = (a.inter + 23) / 24;                  // 24 + 24 columns per workgroup
         if (a.ksplit == 1 && a.tiles > 256 && wide_tiles <= 256 && a.inter % 8 == 0) {
             a.tiles = wide_tiles;
-            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 4, true>), dim3(a.tiles, 1), dim3(SW * 64), 0, stream, a);
+            static const int waves8w = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();
+            if (waves8w) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, true, 8>), dim3(a.tiles, 1), dim3(8 * 64), 0, stream, a);
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 4, true>), dim3(a.tiles, 1), dim3(SW * 64), 0, stream, a);
             return check_launch("linear_stream");
         }
     }
@@ -481,9 +496,16 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         const int pieces = a.K / 64, ks5 = (pieces + SW * 5 - 1) / (SW * 5);
         if (a.ksplit > 1 && a.tiles * a.ksplit > 256 && a.tiles * ks5 <= 256) {
             a.ksplit = ks5;
-            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 5>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
+            static const int waves8r = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();
+            if (waves8r) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 3, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, a);
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 5>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
             return check_launch("linear_stream");
         }
+    }
+    static const int waves8 = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();   // default 8; =4 for A/B
+    if (waves8) {
+        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, a);
+        return check_launch("linear_stream");
     }
     hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
     return check_launch("linear_stream");
