@@ -24,7 +24,11 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA results stay in the architectural VGPRs.  By default hipcc parks accumulators in the AGPR file
 # and pays a v_accvgpr_read/write per element wherever VALU code touches them (softmax on S, rescale of O): 159 such moves in
 # the prefill loop.  Measured: prefill +12 % TFLOP/s, decode step -1.3 %, same results (same-box A/B, round 1).
+# -amdgpu-kernarg-preload-count=14: the first 14 dwords of a kernel's FLAT leading arguments arrive in user SGPRs with the wave
+# (gfx950 kernarg preload) instead of behind an s_load from the kernarg segment: the decode-attention and streaming-GEMM kernels
+# put the operands of their first DMA there (measured: attention call 9.22 -> 9.08 us together with the hoisted table loads).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-mllvm", "-amdgpu-mfma-vgpr-form",
+         "-mllvm", "-amdgpu-kernarg-preload-count=14",
          "-Wall", "-Wno-unused-function", "-Wno-unused-command-line-argument"]
 # rope_store.hip must round RoPE's products and sums separately (bit parity with the reference's elementwise fp32 ops);
 # HIP's default backend contraction ignores the source pragma, so that file is built with contraction off.

@@ -122,7 +122,7 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
         set_error("paged_decode: block_size %d must be a positive multiple of 64, max_blocks %d > 0", block_size, max_blocks);
         return NVH_E_SHAPE;
     }
-    if (q_row_stride % 8 || q_row_stride < (int64_t)h * hd || bt_row_stride < max_blocks) {
+    if (q_row_stride % 8 || q_row_stride < (int64_t)h * hd || bt_row_stride < max_blocks || bt_row_stride > 0x7fffffff) {
         set_error("paged_decode: bad strides q=%lld bt=%lld", (long long)q_row_stride, (long long)bt_row_stride);
         return NVH_E_STRIDE;
     }

@@ -87,8 +87,13 @@ __device__ __forceinline__ void wait_all_but_pieces(int np) {
 // (the half blocks fetch 8 rows; their other 8 MFMA columns are never stored).  4864 / 24 -> 203 equal workgroups on the 256
 // CUs instead of 304 workgroups of 16 + 16 columns, of which 48 CUs carried two.
 // NWV = waves per workgroup (4, or 8 with half the pieces per wave: two waves per SIMD overlap each other's issue phases)
+#define LS_FLAT(a) (a).w, (a).x, (a).K, (a).N, (a).ksplit, (a).tiles, (a).inter, (a).hd, (a)
 template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4, bool WIDE = false, int NWV = 4>
-__global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArgs a) {
+__global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
+    // what the first W DMA and the x loads need comes first and flat: with -amdgpu-kernarg-preload-count these are in SGPRs when the
+    // wave starts instead of behind a kernarg s_load (build.py); the rest of the descriptor follows by reference
+    const uint16_t* __restrict__ p_w, const uint16_t* __restrict__ p_x, const int p_K, const int p_N, const int p_ksplit, const int p_tiles,
+    const int p_inter, const int p_hd, const LinearArgs a) {
     constexpr int SW = NWV;                                                    // (shadows the file-scope default of 4)
     constexpr int TPB = NWV * 64;                                              // threads per workgroup
     constexpr int EPT = (MT * 256 + TPB - 1) / TPB;                            // output element slots per thread
@@ -111,14 +116,14 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
     LS_STAMP(0);
 
     // ---- this wave's K range: the tile's pieces are split over the ksplit workgroups, then over the 4 waves
-    const int P = a.K / 64;
+    const int P = p_K / 64;
     const int split = blockIdx.y;
-    const int wp0 = (int)((int64_t)P * split / a.ksplit), wp1 = (int)((int64_t)P * (split + 1) / a.ksplit);
+    const int wp0 = (int)((int64_t)P * split / p_ksplit), wp1 = (int)((int64_t)P * (split + 1) / p_ksplit);
     const int p0 = __builtin_amdgcn_readfirstlane(wp0 + (wp1 - wp0) * wave / SW);
     const int np = __builtin_amdgcn_readfirstlane(wp0 + (wp1 - wp0) * (wave + 1) / SW - p0);      // 0..PMAX (host guarantees)
-    const int KS = a.K / 32;
-    const int tile_first = MULTI ? (int)((int64_t)a.tiles * blockIdx.x / gridDim.x) : (int)blockIdx.x;
-    const int tile_end = MULTI ? (int)((int64_t)a.tiles * (blockIdx.x + 1) / gridDim.x) : tile_first + 1;
+    const int KS = p_K / 32;
+    const int tile_first = MULTI ? (int)((int64_t)p_tiles * blockIdx.x / gridDim.x) : (int)blockIdx.x;
+    const int tile_end = MULTI ? (int)((int64_t)p_tiles * (blockIdx.x + 1) / gridDim.x) : tile_first + 1;
 
     // ---- W DMA: one instruction = 8 rows x 128 B (one whole line per row); LDS image of a piece = [16 rows][128 B] with the
     // 16-byte chunk order XOR-swizzled on the SOURCE so the operand reads are conflict free (as skinny_gemm.hip)
@@ -127,14 +132,14 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
     auto tile_rows = [&](int tile, int& n0, int& n1, int& head, int& hi0) {
         n1 = 0; head = 0; hi0 = 0;
         if constexpr (EPI == EPI_ROPE) {
-            const int per_head = a.hd / 32;                          // tiles per head: columns i and i + D/2 together
+            const int per_head = p_hd / 32;                          // tiles per head: columns i and i + D/2 together
             head = tile / per_head;
             hi0 = 16 * (tile % per_head);
-            n0 = head * a.hd + hi0;
-            n1 = n0 + a.hd / 2;
+            n0 = head * p_hd + hi0;
+            n1 = n0 + p_hd / 2;
         } else {
             n0 = tile * 16;
-            if constexpr (EPI == EPI_SILU) n1 = a.inter + n0;
+            if constexpr (EPI == EPI_SILU) n1 = p_inter + n0;
         }
     };
     auto issue_w = [&](int tile, int buf) {
@@ -151,12 +156,12 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
                         const int row = 8 * hh + dr;
                         int wrow;                                    // weight row (= output column) this lane fetches
                         if constexpr (WIDE) {
-                            wrow = (nb >> 1) * a.inter + 24 * tile + 16 * (nb & 1) + row;
-                            wrow = wrow < a.N ? wrow : a.N - 1;      // the last tile's half blocks run past the matrix: clamped, unused
+                            wrow = (nb >> 1) * p_inter + 24 * tile + 16 * (nb & 1) + row;
+                            wrow = wrow < p_N ? wrow : p_N - 1;      // the last tile's half blocks run past the matrix: clamped, unused
                         } else {
                             wrow = (nb == 0 ? n0 : n1) + row;
                         }
-                        const uint16_t* src = a.w + (int64_t)wrow * a.K + (p0 + pi) * 64 + (dp ^ ((row >> 1) & 7)) * 8;
+                        const uint16_t* src = p_w + (int64_t)wrow * p_K + (p0 + pi) * 64 + (dp ^ ((row >> 1) & 7)) * 8;
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                          (__attribute__((address_space(3))) void*)(stage + ((pi * NB + nb) * 2 + hh) * 1024), 16, 0, NVH_DMA_AUX);
                     }
@@ -178,10 +183,10 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
                     if constexpr (XPACK) {
-                        araw[2 * pi + j][m] = *reinterpret_cast<const u32x4*>(a.x + (((int64_t)m * KS + ks) * 64 + lane) * 8);
+                        araw[2 * pi + j][m] = *reinterpret_cast<const u32x4*>(p_x + (((int64_t)m * KS + ks) * 64 + lane) * 8);
                     } else {
                         const int r = 16 * m + lq;                   // rows past M repeat the last row; discarded
-                        araw[2 * pi + j][m] = *reinterpret_cast<const u32x4*>(a.x + (int64_t)(r < a.M ? r : a.M - 1) * a.x_stride + ks * 32 + lg * 8);
+                        araw[2 * pi + j][m] = *reinterpret_cast<const u32x4*>(p_x + (int64_t)(r < a.M ? r : a.M - 1) * a.x_stride + ks * 32 + lg * 8);
                     }
                 }
             }
@@ -210,9 +215,9 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
             const int row = min(16 * (v >> 8) + 4 * (l >> 4) + (v & 3), a.M - 1);
             rp_b1[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f;
             rp_b2[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n1 + c]) : 0.f;
-            const float* cs = a.cos_sin + a.positions[row] * a.hd;
+            const float* cs = a.cos_sin + a.positions[row] * p_hd;
             rp_co[j] = cs[hi0 + c];
-            rp_si[j] = cs[a.hd / 2 + hi0 + c];
+            rp_si[j] = cs[p_hd / 2 + hi0 + c];
             rp_slot[j] = head >= a.h ? a.slots[row] : 0;
         }
     }
@@ -305,9 +310,9 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
                 for (int w = 0; w < SW; ++w) rowss[j] += lds_ss[w][mt][4 * (l >> 4) + r];
             }
         }
-        if (a.ksplit > 1) {
+        if (p_ksplit > 1) {
             // ---- split-K: publish the partial, take a ticket; the last arriver sums all partials in split order
-            float* const part = a.ws + ((int64_t)tile * a.ksplit + split) * PSTRIDE;
+            float* const part = a.ws + ((int64_t)tile * p_ksplit + split) * PSTRIDE;
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 if (tid + TPB * j < MT * 256) {                  // (8 waves, one row tile: the upper half of the threads owns no element)
@@ -327,13 +332,13 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
             __syncthreads();
             if (tid == 0) {
                 const unsigned old = __hip_atomic_fetch_add(&a.counters[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)a.ksplit - 1)
+                if (old == (unsigned)p_ksplit - 1)
                     __hip_atomic_store(&a.counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
                 *lds_ticket = old;
             }
             __syncthreads();
-            if (*lds_ticket != (unsigned)a.ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
-            const float* const base = a.ws + (int64_t)tile * a.ksplit * PSTRIDE;
+            if (*lds_ticket != (unsigned)p_ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
+            const float* const base = a.ws + (int64_t)tile * p_ksplit * PSTRIDE;
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 const int v = tid + TPB * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
@@ -341,18 +346,18 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
                 for (int nb = 0; nb < NB; ++nb) s[j][nb] = 0.f;
                 rowss[j] = 0.f;
                 if (v >= MT * 256) continue;
-                for (int sp0 = 0; sp0 < a.ksplit; sp0 += 8) {
+                for (int sp0 = 0; sp0 < p_ksplit; sp0 += 8) {
                     float tmp[8][NB + 1];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        const int sp = sp0 + i < a.ksplit ? sp0 + i : a.ksplit - 1;
+                        const int sp = sp0 + i < p_ksplit ? sp0 + i : p_ksplit - 1;
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb) tmp[i][nb] = ld_sc1(base + (int64_t)sp * PSTRIDE + nb * MT * 256 + v);
                         tmp[i][NB] = NORM == 2 ? ld_sc1(base + (int64_t)sp * PSTRIDE + NB * MT * 256 + mt * 16 + 4 * (l >> 4) + r) : 0.f;
                     }
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
-                        if (sp0 + i < a.ksplit) {
+                        if (sp0 + i < p_ksplit) {
 #pragma unroll
                             for (int nb = 0; nb < NB; ++nb) s[j][nb] += tmp[i][nb];
                             rowss[j] += tmp[i][NB];
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) y[nb] = s[j][nb];
             if constexpr (NORM == 2) {                                 // x.(g*W)^T * rsqrt(mean(x^2)+eps) == RMSNorm(x).W^T without the two bf16 roundings
-                const float inv_row = rsqrtf(rowss[j] / a.K + a.norm_eps);
+                const float inv_row = rsqrtf(rowss[j] / p_K + a.norm_eps);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) y[nb] *= inv_row;
             }
@@ -382,23 +387,23 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {                           // full block (16 columns), half block (8 columns)
                     const int col = 24 * tile + 16 * hb + c;
-                    if ((hb == 1 && c >= 8) || col >= a.inter) continue;
+                    if ((hb == 1 && c >= 8) || col >= p_inter) continue;
                     const float g = (float)(__bf16)y[hb], u = (float)(__bf16)y[2 + hb];
                     const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
                     if (out) out[(int64_t)row * a.out_stride + col] = o;
-                    if (a.out_packed) a.out_packed[pack_index(row, col, a.inter)] = __builtin_bit_cast(uint16_t, o);
+                    if (a.out_packed) a.out_packed[pack_index(row, col, p_inter)] = __builtin_bit_cast(uint16_t, o);
                 }
             } else if constexpr (EPI == EPI_SILU) {
                 const float g = (float)(__bf16)y[0], u = (float)(__bf16)y[1];          // the projection output is bf16 in the reference
                 const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
                 if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
-                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.inter)] = __builtin_bit_cast(uint16_t, o);
+                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, p_inter)] = __builtin_bit_cast(uint16_t, o);
             } else if constexpr (EPI == EPI_RESADD) {
                 __bf16* p = out + (int64_t)row * a.out_stride + n0 + c;
                 const float old = MULTI ? (float)*p : (float)__builtin_bit_cast(__bf16, resid[j]);
                 const __bf16 o = (__bf16)(y[0] + old);
                 *p = o;
-                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.N)] = __builtin_bit_cast(uint16_t, o);
+                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
             } else if constexpr (EPI == EPI_ROPE) {
                 float x1 = y[0], x2 = y[1];
                 if (a.bias) {                                              // (x + 0.f would also be exact, but keep the no-bias path add-free)
@@ -416,23 +421,23 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(const LinearArg
                     y2 = p3 + p4;
                 }
                 if (head < a.h) {
-                    __bf16* q = out + (int64_t)row * a.out_stride + head * a.hd + i;
+                    __bf16* q = out + (int64_t)row * a.out_stride + head * p_hd + i;
                     q[0] = (__bf16)y1;
-                    q[a.hd / 2] = (__bf16)y2;
+                    q[p_hd / 2] = (__bf16)y2;
                 } else {
                     const int slot = rp_slot[j];
                     if (slot >= 0) {
                         const bool is_v = head >= a.h + a.kvh;
                         __bf16* dst = reinterpret_cast<__bf16*>(is_v ? a.v_cache : a.k_cache) +
-                                      ((int64_t)slot * a.kvh + (head - a.h - (is_v ? a.kvh : 0))) * a.hd + i;
+                                      ((int64_t)slot * a.kvh + (head - a.h - (is_v ? a.kvh : 0))) * p_hd + i;
                         dst[0] = (__bf16)y1;
-                        dst[a.hd / 2] = (__bf16)y2;
+                        dst[p_hd / 2] = (__bf16)y2;
                     }
                 }
             } else {
                 const __bf16 o = (__bf16)(y[0] + (a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f));
                 if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
-                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, a.N)] = __builtin_bit_cast(uint16_t, o);
+                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
                 if (a.cand_val && (float)o > best_v[j]) {                  // tiles ascend: a strict > keeps the lowest column
                     best_v[j] = (float)o;
                     best_i[j] = n0 + c;
@@ -474,8 +479,8 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
     if (multi) {
         if constexpr (EPI == EPI_NONE) {
             static const int waves8m = [] { const char* e = getenv("NVH_GEMM_WAVES_MULTI"); return e ? atoi(e) == 8 : 0; }();   // A/B knob
-            if (waves8m) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true, 2, false, 8>), dim3(512), dim3(8 * 64), 0, stream, a);
-            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, a);
+            if (waves8m) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true, 2, false, 8>), dim3(512), dim3(8 * 64), 0, stream, LS_FLAT(a));
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, LS_FLAT(a));
         }
         return check_launch("linear_stream");
     }
@@ -484,8 +489,8 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         if (a.ksplit == 1 && a.tiles > 256 && wide_tiles <= 256 && a.inter % 8 == 0) {
             a.tiles = wide_tiles;
             static const int waves8w = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();
-            if (waves8w) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, true, 8>), dim3(a.tiles, 1), dim3(8 * 64), 0, stream, a);
-            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 4, true>), dim3(a.tiles, 1), dim3(SW * 64), 0, stream, a);
+            if (waves8w) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, true, 8>), dim3(a.tiles, 1), dim3(8 * 64), 0, stream, LS_FLAT(a));
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 4, true>), dim3(a.tiles, 1), dim3(SW * 64), 0, stream, LS_FLAT(a));
             return check_launch("linear_stream");
         }
     }
@@ -497,17 +502,17 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         if (a.ksplit > 1 && a.tiles * a.ksplit > 256 && a.tiles * ks5 <= 256) {
             a.ksplit = ks5;
             static const int waves8r = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();
-            if (waves8r) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 3, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, a);
-            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 5>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
+            if (waves8r) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 3, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, LS_FLAT(a));
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 5>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, LS_FLAT(a));
             return check_launch("linear_stream");
         }
     }
     static const int waves8 = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();   // default 8; =4 for A/B
     if (waves8) {
-        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, a);
+        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, LS_FLAT(a));
         return check_launch("linear_stream");
     }
-    hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, a);
+    hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, LS_FLAT(a));
     return check_launch("linear_stream");
 }
 

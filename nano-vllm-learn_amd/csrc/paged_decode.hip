@@ -509,7 +509,12 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
 //     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
 template <int D, int NW>
-__global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const DecodeArgs a, const int G) {
+__global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
+    // the operands on the way to the first DMA come first and flat: with -amdgpu-kernarg-preload-count they are in SGPRs when the
+    // wave starts (14 user SGPRs), instead of behind a kernarg s_load; the rest of the descriptor follows by reference
+    const int32_t* __restrict__ p_context_lens, const int32_t* __restrict__ p_block_tables, const uint16_t* __restrict__ p_k_cache,
+    const uint16_t* __restrict__ p_v_cache, const int p_kvh, const int p_block_size, const int p_max_blocks, const int p_chunks,
+    const int p_bt_stride, const int G, const DecodeArgs a) {
     // NW waves share a pass of SPLIT tokens: NW = 4 -> 64-token (D=64) / 32-token (D=128) tiles; NW = 8 (D=64 only) -> 32-token
     // tiles, two waves per SIMD covering each other's LDS / MFMA latencies, same LDS footprint
     constexpr int MW = NW;
@@ -526,13 +531,21 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
     float* const lds_ml = reinterpret_cast<float*>(lds_q + QI * 1024);              // [wave][max | sum][16 heads]
     unsigned* const lds_ticket = reinterpret_cast<unsigned*>(lds_q + QI * 1024 + MW * 2 * 16 * 4);
 
-    const int split = blockIdx.y, kh = blockIdx.x % a.kvh, b = blockIdx.x / a.kvh;   // `split` = chunk index
-    const int NC = a.chunks;
+    const int split = blockIdx.y, kh = blockIdx.x % p_kvh, b = blockIdx.x / p_kvh;   // `split` = chunk index
+    const int NC = p_chunks;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     NVH_STAMP(0);
-    const int ctx = a.context_lens[b];
+    // the block ids of the first two passes do not depend on the context length (the index is clamped to the table row, whose
+    // entries past the live range are never used): fetch them together with it, one scalar round trip instead of two in a row
+    const int64_t bt_row = (int64_t)b * p_bt_stride;
+    const int wtok = wave * WT;
+    int pass = split;
+    int tok0 = pass * SPLIT + wtok;
+    int bid = load_uniform_i32(p_block_tables + bt_row + min(tok0 / p_block_size, p_max_blocks - 1));
+    int bid_next = load_uniform_i32(p_block_tables + bt_row + min((tok0 + NC * SPLIT) / p_block_size, p_max_blocks - 1));
+    const int ctx = load_uniform_i32(p_context_lens + b);
     const int live_passes = (ctx + SPLIT - 1) / SPLIT;
     if (split >= live_passes) {
         if (split == 0) {                                     // ctx == 0 (padding row): zeros, as the oracle
@@ -545,38 +558,32 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
         }
         return;                                               // whole workgroup, before any barrier
     }
-    const int64_t bt_row = (int64_t)b * a.bt_row_stride;
     // this wave's tile in pass p starts at token p*SPLIT + wave*WT; block ids are fetched one pass ahead
-    const int wtok = wave * WT;
-    int pass = split;
-    int tok0 = pass * SPLIT + wtok;
-    int bid = load_uniform_i32(a.block_tables + bt_row + min(tok0 / a.block_size, a.max_blocks - 1));
-    int bid_next = load_uniform_i32(a.block_tables + bt_row + min((tok0 + NC * SPLIT) / a.block_size, a.max_blocks - 1));
     NVH_STAMP(1);
 
     unsigned char* const lds_w = lds + wave * WAVE_LDS;
     const int lq = lane & 15;                                 // head column of the MFMA tiles
     const int lg = lane >> 4;                                 // lane group: k-block of operands / row block of C
     const int dp = lane % LPT, dr = lane / LPT;               // DMA: chunk position / row inside one instruction
-    const int64_t row = (int64_t)a.kvh * D;                   // elements per token (all kv heads)
+    const int64_t row = (int64_t)p_kvh * D;                   // elements per token (all kv heads)
 
     auto issue_kv = [&](int t0, int block_id, int buf) {      // K then V image of the tile starting at token t0
-        const int off0 = t0 - (t0 / a.block_size) * a.block_size;
-        const int64_t base = ((int64_t)block_id * a.block_size + off0) * row + (int64_t)kh * D;
+        const int off0 = t0 - (t0 / p_block_size) * p_block_size;
+        const int64_t base = ((int64_t)block_id * p_block_size + off0) * row + (int64_t)kh * D;
         const int last = ctx - t0 - 1;                        // rows past the live range repeat the last live row
         unsigned char* const kimg = lds_w + buf * WAVE_BYTES;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int T = i * TPI + dr;
             const int Tc = T < last ? T : last;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.k_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_k_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
                                              (__attribute__((address_space(3))) void*)(kimg + i * 1024), 16, 0, NVH_DMA_AUX);
         }
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int T = i * TPI + dr;
             const int Tc = T < last ? T : last;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.v_cache + base + Tc * row + (dp ^ chunk_swizzle_v<LPT>(T)) * 8),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_v_cache + base + Tc * row + (dp ^ chunk_swizzle_v<LPT>(T)) * 8),
                                              (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, NVH_DMA_AUX);
         }
     };
@@ -606,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
             int bid_nn = 0;
             if (has_next) {
                 issue_kv(tok_next, bid_next, buf ^ 1);
-                bid_nn = load_uniform_i32(a.block_tables + bt_row + min((tok_next + NC * SPLIT) / a.block_size, a.max_blocks - 1));
+                bid_nn = load_uniform_i32(p_block_tables + bt_row + min((tok_next + NC * SPLIT) / p_block_size, p_max_blocks - 1));
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");      // q and this pass's K landed
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
     }
     if (live_chunks > 1) {
         const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
-        float* const recs = a.ws_acc + ((int64_t)b * a.kvh + kh) * NC * rec;
+        float* const recs = a.ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
         float* const mine = recs + (int64_t)split * rec;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -765,7 +772,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(const Dec
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            unsigned* const ctr = a.counters + (int64_t)b * a.kvh + kh;
+            unsigned* const ctr = a.counters + (int64_t)b * p_kvh + kh;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *lds_ticket = old;
@@ -904,11 +911,13 @@ int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
     dim3 grid(a.kvh * a.batch, a.chunks);
     if constexpr (D == 64) {
         if (waves == 8) {
-            hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a, g);
+            hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
+                               a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, g, a);
             return check_launch("paged_decode_chunked");
         }
     }
-    hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 4>), grid, dim3(4 * 64), 0, stream, a, g);
+    hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 4>), grid, dim3(4 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache, a.kvh,
+                       a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, g, a);
     return check_launch("paged_decode_chunked");
 }
 
