@@ -339,32 +339,39 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             __syncthreads();
             if (*lds_ticket != (unsigned)p_ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
             const float* const base = a.ws + (int64_t)tile * p_ksplit * PSTRIDE;
+            // partials are requested SB splits at a time, all loads of a batch in flight together; up to four splits (the
+            // balanced down_proj shape) are one batch instead of an 8-wide one with half of it repeated
+            auto sum_splits = [&](auto sb_tag) {
+                constexpr int SB = decltype(sb_tag)::value;
 #pragma unroll
-            for (int j = 0; j < EPT; ++j) {
-                const int v = tid + TPB * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
+                for (int j = 0; j < EPT; ++j) {
+                    const int v = tid + TPB * j, mt = v >> 8, l = (v >> 2) & 63, r = v & 3;
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) s[j][nb] = 0.f;
-                rowss[j] = 0.f;
-                if (v >= MT * 256) continue;
-                for (int sp0 = 0; sp0 < p_ksplit; sp0 += 8) {
-                    float tmp[8][NB + 1];
+                    for (int nb = 0; nb < NB; ++nb) s[j][nb] = 0.f;
+                    rowss[j] = 0.f;
+                    if (v >= MT * 256) continue;
+                    for (int sp0 = 0; sp0 < p_ksplit; sp0 += SB) {
+                        float tmp[SB][NB + 1];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int sp = sp0 + i < p_ksplit ? sp0 + i : p_ksplit - 1;
+                        for (int i = 0; i < SB; ++i) {
+                            const int sp = sp0 + i < p_ksplit ? sp0 + i : p_ksplit - 1;
 #pragma unroll
-                        for (int nb = 0; nb < NB; ++nb) tmp[i][nb] = ld_sc1(base + (int64_t)sp * PSTRIDE + nb * MT * 256 + v);
-                        tmp[i][NB] = NORM == 2 ? ld_sc1(base + (int64_t)sp * PSTRIDE + NB * MT * 256 + mt * 16 + 4 * (l >> 4) + r) : 0.f;
-                    }
+                            for (int nb = 0; nb < NB; ++nb) tmp[i][nb] = ld_sc1(base + (int64_t)sp * PSTRIDE + nb * MT * 256 + v);
+                            tmp[i][NB] = NORM == 2 ? ld_sc1(base + (int64_t)sp * PSTRIDE + NB * MT * 256 + mt * 16 + 4 * (l >> 4) + r) : 0.f;
+                        }
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        if (sp0 + i < p_ksplit) {
+                        for (int i = 0; i < SB; ++i) {
+                            if (sp0 + i < p_ksplit) {
 #pragma unroll
-                            for (int nb = 0; nb < NB; ++nb) s[j][nb] += tmp[i][nb];
-                            rowss[j] += tmp[i][NB];
+                                for (int nb = 0; nb < NB; ++nb) s[j][nb] += tmp[i][nb];
+                                rowss[j] += tmp[i][NB];
+                            }
                         }
                     }
                 }
-            }
+            };
+            if (p_ksplit <= 4) sum_splits(std::integral_constant<int, 4>{});
+            else sum_splits(std::integral_constant<int, 8>{});
         }
         if (tile == tile_first) LS_STAMP(5);
         // ---- epilogue

@@ -44,8 +44,17 @@ namespace {
 // Diagnostic build only (-DNVH_STAMPS, tools/probes/stamp_decode.py): clock stamps per wave into a debug
 // buffer that nothing else reads.  Never compiled into the shipped library.
 #ifdef NVH_STAMPS
-#define NVH_STAMP(k)                                                                                     \
+#define NVH_STAMP(k) NVH_STAMP_IF(NVH_STAMP_HEAD(k), k)
+#ifdef NVH_STAMPS_TAIL                          // slots 1..5 follow the hand-off tail of the chunked kernel instead of its first pass
+#define NVH_STAMP_HEAD(k) ((k) == 0 || (k) >= 6)
+#define NVH_TSTAMP(k) NVH_STAMP_IF(true, k)
+#else
+#define NVH_STAMP_HEAD(k) true
+#define NVH_TSTAMP(k) do {} while (0)
+#endif
+#define NVH_STAMP_IF(on, k)                                                                              \
     do {                                                                                                 \
+        if (!(on)) break;                                                                                \
         unsigned long long t_;                                                                           \
         __builtin_amdgcn_sched_barrier(0);                                                               \
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
@@ -55,6 +64,7 @@ namespace {
     } while (0)
 #else
 #define NVH_STAMP(k) do {} while (0)
+#define NVH_TSTAMP(k) do {} while (0)
 #endif
 
 constexpr int WAVES = 8;                        // VALU kernel: waves per workgroup
@@ -743,17 +753,30 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         Mv[e] = -INFINITY; Lv[e] = 0.f; Ov[e] = 0.f;
         if (idx < G * D) {
             const int g = idx / D;
-            float M = -INFINITY;
-            for (int w = 0; w < n_waves; ++w) M = fmaxf(M, lds_ml[(w * 2 + 0) * 16 + g]);
+            // every wave's (max, sum, O) requested at once (dead waves re-read the last live one and are masked): one LDS
+            // latency instead of one per wave
+            float mw[WAVES], lw[WAVES], ow[WAVES];
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const int wc = w < n_waves ? w : n_waves - 1;
+                mw[w] = lds_ml[(wc * 2 + 0) * 16 + g];
+                lw[w] = lds_ml[(wc * 2 + 1) * 16 + g];
+                ow[w] = reinterpret_cast<const float*>(lds + wc * WAVE_LDS)[idx];
+            }
+            float M = mw[0];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) M = fmaxf(M, mw[w]);      // (a repeated wave does not change the max)
             float ov = 0.f, L = 0.f;
-            for (int w = 0; w < n_waves; ++w) {
-                const float f = fast_exp2(lds_ml[(w * 2 + 0) * 16 + g] - M);
-                ov = fmaf(reinterpret_cast<const float*>(lds + w * WAVE_LDS)[idx], f, ov);
-                L = fmaf(lds_ml[(w * 2 + 1) * 16 + g], f, L);
+#pragma unroll
+            for (int w = 0; w < WAVES; ++w) {
+                const float f = w < n_waves ? fast_exp2(mw[w] - M) : 0.f;
+                ov = fmaf(ow[w], f, ov);
+                L = fmaf(lw[w], f, L);
             }
             Mv[e] = M; Lv[e] = L; Ov[e] = ov;
         }
     }
+    NVH_TSTAMP(1);
     if (live_chunks > 1) {
         const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
         float* const recs = a.ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
@@ -769,8 +792,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                 }
             }
         }
+        NVH_TSTAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        NVH_TSTAMP(3);
         if (tid == 0) {
             unsigned* const ctr = a.counters + (int64_t)b * p_kvh + kh;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -778,42 +803,51 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             *lds_ticket = old;
         }
         __syncthreads();
+        NVH_TSTAMP(4);
         if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
+        // records are requested CB at a time (every load of a batch in flight together); four chunks, the common shape of a
+        // full launch, are one batch of 12 loads per thread rather than an 8-wide batch with half of it repeated
+        auto merge_chunks = [&](auto cb_tag) {
+            constexpr int CB = decltype(cb_tag)::value;
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + e * WAVES * 64;
-            if (idx < G * D) {
-                const int g = idx / D;
-                float M = -INFINITY, ov = 0.f, L = 0.f;
-                for (int c0 = 0; c0 < live_chunks; c0 += 8) {
-                    float mv[8], lv[8], av[8];
+            for (int e = 0; e < EPT; ++e) {
+                const int idx = tid + e * WAVES * 64;
+                if (idx < G * D) {
+                    const int g = idx / D;
+                    float M = -INFINITY, ov = 0.f, L = 0.f;
+                    for (int c0 = 0; c0 < live_chunks; c0 += CB) {
+                        float mv[CB], lv[CB], av[CB];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
-                        const float* r = recs + (int64_t)c * rec;
-                        mv[i] = ld_sc1(r + G * D + g);
-                        lv[i] = ld_sc1(r + G * D + G + g);
-                        av[i] = ld_sc1(r + idx);
-                    }
-                    float Mc = M;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (c0 + i < live_chunks) Mc = fmaxf(Mc, mv[i]);
-                    const float fo = fast_exp2(M - Mc);        // M = -inf on the first group -> 0
-                    ov *= fo;
-                    L *= fo;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        if (c0 + i < live_chunks) {
-                            const float f = fast_exp2(mv[i] - Mc);
-                            ov = fmaf(av[i], f, ov);
-                            L = fmaf(lv[i], f, L);
+                        for (int i = 0; i < CB; ++i) {
+                            const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
+                            const float* r = recs + (int64_t)c * rec;
+                            mv[i] = ld_sc1(r + G * D + g);
+                            lv[i] = ld_sc1(r + G * D + G + g);
+                            av[i] = ld_sc1(r + idx);
                         }
-                    M = Mc;
+                        float Mc = M;
+#pragma unroll
+                        for (int i = 0; i < CB; ++i)
+                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, mv[i]);
+                        const float fo = fast_exp2(M - Mc);        // M = -inf on the first group -> 0
+                        ov *= fo;
+                        L *= fo;
+#pragma unroll
+                        for (int i = 0; i < CB; ++i)
+                            if (c0 + i < live_chunks) {
+                                const float f = fast_exp2(mv[i] - Mc);
+                                ov = fmaf(av[i], f, ov);
+                                L = fmaf(lv[i], f, L);
+                            }
+                        M = Mc;
+                    }
+                    Lv[e] = L; Ov[e] = ov;
                 }
-                Lv[e] = L; Ov[e] = ov;
             }
-        }
+        };
+        if (live_chunks <= 4) merge_chunks(std::integral_constant<int, 4>{});
+        else merge_chunks(std::integral_constant<int, 8>{});
+        NVH_TSTAMP(5);
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {

@@ -8,9 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 CSRC = os.path.join(ROOT, "nano-vllm-learn_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "probes", "libnvh_attn_stamps.so")
 
-def build():
+def build(tail=False):
     srcs = [os.path.join(CSRC, f) for f in ("api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip")]
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNVH_STAMPS", "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNVH_STAMPS", *(["-DNVH_STAMPS_TAIL"] if tail else []), "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
+                    "-mllvm", "-amdgpu-kernarg-preload-count=14",
                     "-Wno-unused-command-line-argument", *srcs, "-o", OUT], check=True)
 
 def main():
@@ -18,9 +19,10 @@ def main():
     ap.add_argument("--batch", type=int, default=32); ap.add_argument("--ctx", type=int, default=1536)
     ap.add_argument("--heads", type=int, default=14); ap.add_argument("--kv-heads", type=int, default=2)
     ap.add_argument("--head-dim", type=int, default=64); ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--tail", action="store_true", help="slots 1..5 follow the hand-off tail instead of the first pass (always rebuilds)")
     args = ap.parse_args()
-    if args.build_only or not os.path.exists(OUT):
-        build()
+    if args.build_only or args.tail or not os.path.exists(OUT):
+        build(args.tail)
         if args.build_only: return
     lib = ctypes.CDLL(OUT)
     b, h, kvh, d, bs = args.batch, args.heads, args.kv_heads, args.head_dim, 256
@@ -45,20 +47,38 @@ def main():
     for rep in range(3):
         for l in range(layers): call(l)
     torch.cuda.synchronize()
+    stamps.zero_()                                                             # the timeline of ONE call (the last arriver differs per call)
+    call(0)
+    torch.cuda.synchronize()
     st = stamps.cpu().numpy().reshape(-1, waves, 8).astype(np.float64) * 0.01     # us
     st = st[st[:, 0, 1] > 0]                                                   # live workgroups only
     t0 = st[:, :, 0].min()
-    names = ["start", "scalars+branch", "first loads issued", "first K landed", "first QK+softmax done", "first V landed", "all passes done",
+    names = ["start", "waves merged in LDS", "record stores issued", "stores acknowledged + barrier", "ticket returned + barrier", "records read + merged (last arriver)",
+             "all passes done", "written (last arriver)"] if args.tail else ["start", "scalars+branch", "first loads issued", "first K landed", "first QK+softmax done", "first V landed", "all passes done",
              "merged + written (last arriver)"]
     print(f"live workgroups {st.shape[0]}, kernel span {st[:, :, 7].max() - t0:.2f} us (first wave start -> last wave end)")
-    for k, n in enumerate(names):
+    order = [0, 6, 1, 2, 3, 4, 5, 7] if args.tail else list(range(8))
+    for pos, k in enumerate(order):
+        n = names[k]
         ok = st[:, :, k] > 0
         v = (st[:, :, k] - t0)[ok]
         line = f"  {k} {n:<32} abs: min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}"
-        if k:
-            both = ok & (st[:, :, k - 1] > 0)
-            d = (st[:, :, k] - st[:, :, k - 1])[both]
+        if pos:
+            kp = order[pos - 1]
+            both = ok & (st[:, :, kp] > 0)
+            d = (st[:, :, k] - st[:, :, kp])[both]
             line += f"   delta vs prev: med {np.median(d):5.2f} max {d.max():5.2f}"
         print(line)
+    if args.tail:                                                              # per-workgroup critical path (the barrier hides wave skew)
+        done = st[:, :, 6].max(axis=1); first_done = np.where(st[:, :, 6] > 0, st[:, :, 6], np.inf).min(axis=1)
+        merged = st[:, :, 1].max(axis=1)
+        print(f"  per workgroup: wave skew at the end of the passes med {np.median(done - first_done):.2f} max {(done - first_done).max():.2f}; "
+              f"last wave done -> merged med {np.median(merged - done):.2f} max {(merged - done).max():.2f}")
+        last = st[:, 0, 5] > 0
+        seq = [6, 1, 2, 3, 4, 5, 7]
+        tl = [np.median(st[last][:, :, k].max(axis=1) - t0) for k in seq]
+        print("  last arrivers (median abs, max over waves):", " ".join(f"{names[k].split(' (')[0]}={v:.2f}" for k, v in zip(seq, tl)))
+        starts = st[:, :, 0].min(axis=1) - t0
+        print(f"  workgroup start: med {np.median(starts):.2f} p90 {np.percentile(starts, 90):.2f} max {starts.max():.2f}; passes per workgroup differ (ctx {args.ctx})")
 if __name__ == "__main__":
     main()
