@@ -46,6 +46,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int SW = 4;                          // waves per workgroup
+constexpr unsigned kMultiWgs = 512;            // workgroups of a MULTI launch (the LM head): two per CU, a power of two
 constexpr int PMAX = 4;                        // pieces (2 k-steps = 64 K-elements = one 128-byte line per weight row) per wave
 
 #ifdef NVH_STAMPS
@@ -87,13 +88,14 @@ __device__ __forceinline__ void wait_all_but_pieces(int np) {
 // (the half blocks fetch 8 rows; their other 8 MFMA columns are never stored).  4864 / 24 -> 203 equal workgroups on the 256
 // CUs instead of 304 workgroups of 16 + 16 columns, of which 48 CUs carried two.
 // NWV = waves per workgroup (4, or 8 with half the pieces per wave: two waves per SIMD overlap each other's issue phases)
-#define LS_FLAT(a) (a).w, (a).x, (a).K, (a).N, (a).ksplit, (a).tiles, (a).inter, (a).hd, (a)
+// (p_pq, p_pr) = K pieces per split: quotient and remainder, so that no workgroup divides on the way to its first DMA
+#define LS_FLAT(a) (a).w, (a).x, (a).K, (a).N, (a).ksplit, (a).tiles, (a).inter, (a).hd, ((a).K / 64) / (a).ksplit, ((a).K / 64) % (a).ksplit, (a)
 template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4, bool WIDE = false, int NWV = 4>
 __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     // what the first W DMA and the x loads need comes first and flat: with -amdgpu-kernarg-preload-count these are in SGPRs when the
     // wave starts instead of behind a kernarg s_load (build.py); the rest of the descriptor follows by reference
     const uint16_t* __restrict__ p_w, const uint16_t* __restrict__ p_x, const int p_K, const int p_N, const int p_ksplit, const int p_tiles,
-    const int p_inter, const int p_hd, const LinearArgs a) {
+    const int p_inter, const int p_hd, const int p_pq, const int p_pr, const LinearArgs a) {
     constexpr int SW = NWV;                                                    // (shadows the file-scope default of 4)
     constexpr int TPB = NWV * 64;                                              // threads per workgroup
     constexpr int EPT = (MT * 256 + TPB - 1) / TPB;                            // output element slots per thread
@@ -116,14 +118,14 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     LS_STAMP(0);
 
     // ---- this wave's K range: the tile's pieces are split over the ksplit workgroups, then over the 4 waves
-    const int P = p_K / 64;
+    // (the first p_pr splits carry one piece more; integer division costs hundreds of cycles here, in front of the first DMA)
     const int split = blockIdx.y;
-    const int wp0 = (int)((int64_t)P * split / p_ksplit), wp1 = (int)((int64_t)P * (split + 1) / p_ksplit);
+    const int wp0 = p_pq * split + min(split, p_pr), wp1 = wp0 + p_pq + (split < p_pr ? 1 : 0);
     const int p0 = __builtin_amdgcn_readfirstlane(wp0 + (wp1 - wp0) * wave / SW);
     const int np = __builtin_amdgcn_readfirstlane(wp0 + (wp1 - wp0) * (wave + 1) / SW - p0);      // 0..PMAX (host guarantees)
     const int KS = p_K / 32;
-    const int tile_first = MULTI ? (int)((int64_t)p_tiles * blockIdx.x / gridDim.x) : (int)blockIdx.x;
-    const int tile_end = MULTI ? (int)((int64_t)p_tiles * (blockIdx.x + 1) / gridDim.x) : tile_first + 1;
+    const int tile_first = MULTI ? (int)((unsigned)(p_tiles * blockIdx.x) / kMultiWgs) : (int)blockIdx.x;   // (tiles * 512 < 2^31: host)
+    const int tile_end = MULTI ? (int)((unsigned)(p_tiles * (blockIdx.x + 1)) / kMultiWgs) : tile_first + 1;
 
     // ---- W DMA: one instruction = 8 rows x 128 B (one whole line per row); LDS image of a piece = [16 rows][128 B] with the
     // 16-byte chunk order XOR-swizzled on the SOURCE so the operand reads are conflict free (as skinny_gemm.hip)
@@ -132,9 +134,9 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     auto tile_rows = [&](int tile, int& n0, int& n1, int& head, int& hi0) {
         n1 = 0; head = 0; hi0 = 0;
         if constexpr (EPI == EPI_ROPE) {
-            const int per_head = p_hd / 32;                          // tiles per head: columns i and i + D/2 together
-            head = tile / per_head;
-            hi0 = 16 * (tile % per_head);
+            const int ph_shift = p_hd == 128 ? 2 : 1;                // tiles per head (hd / 32 = 2 or 4): columns i and i + D/2 together
+            head = tile >> ph_shift;
+            hi0 = 16 * (tile & ((1 << ph_shift) - 1));
             n0 = head * p_hd + hi0;
             n1 = n0 + p_hd / 2;
         } else {
@@ -486,8 +488,8 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
     if (multi) {
         if constexpr (EPI == EPI_NONE) {
             static const int waves8m = [] { const char* e = getenv("NVH_GEMM_WAVES_MULTI"); return e ? atoi(e) == 8 : 0; }();   // A/B knob
-            if (waves8m) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true, 2, false, 8>), dim3(512), dim3(8 * 64), 0, stream, LS_FLAT(a));
-            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(512), dim3(SW * 64), 0, stream, LS_FLAT(a));
+            if (waves8m) hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true, 2, false, 8>), dim3(kMultiWgs), dim3(8 * 64), 0, stream, LS_FLAT(a));
+            else hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, true>), dim3(kMultiWgs), dim3(SW * 64), 0, stream, LS_FLAT(a));
         }
         return check_launch("linear_stream");
     }
@@ -551,7 +553,7 @@ int tiles_of(int n, int inter, int h, int kvh, int hd, int epi) {
 int linear_stream_candidate_groups(int n, int k) {
     if (k % 64 != 0 || k / 64 > SW * PMAX || n % 16 != 0) return 0;    // one workgroup must see the whole K range
     const int tiles = n / 16;
-    return tiles > 1024 ? 512 : tiles;
+    return tiles > 1024 ? (int)kMultiWgs : tiles;
 }
 
 // counters [tiles] (rounded to 256 B) then partial records [tiles][ksplit][NB*MT*256 + MT*16] fp32; 0 when K needs no split

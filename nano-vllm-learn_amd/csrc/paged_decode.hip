@@ -524,7 +524,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     // wave starts (14 user SGPRs), instead of behind a kernarg s_load; the rest of the descriptor follows by reference
     const int32_t* __restrict__ p_context_lens, const int32_t* __restrict__ p_block_tables, const uint16_t* __restrict__ p_k_cache,
     const uint16_t* __restrict__ p_v_cache, const int p_kvh, const int p_block_size, const int p_max_blocks, const int p_chunks,
-    const int p_bt_stride, const int G, const DecodeArgs a) {
+    const int p_bt_stride, const int p_bs_shift, const DecodeArgs a, const int G) {
     // NW waves share a pass of SPLIT tokens: NW = 4 -> 64-token (D=64) / 32-token (D=128) tiles; NW = 8 (D=64 only) -> 32-token
     // tiles, two waves per SIMD covering each other's LDS / MFMA latencies, same LDS footprint
     constexpr int MW = NW;
@@ -541,7 +541,11 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     float* const lds_ml = reinterpret_cast<float*>(lds_q + QI * 1024);              // [wave][max | sum][16 heads]
     unsigned* const lds_ticket = reinterpret_cast<unsigned*>(lds_q + QI * 1024 + MW * 2 * 16 * 4);
 
-    const int split = blockIdx.y, kh = blockIdx.x % p_kvh, b = blockIdx.x / p_kvh;   // `split` = chunk index
+    // grid (kv head, sequence, chunk): the same linear workgroup order as (kv head + kvh * sequence, chunk) without the division;
+    // block_size is a power of two in every engine configuration: p_bs_shift >= 0 then replaces the divisions by it (each a
+    // ~30-instruction sequence on the way to the first DMA)
+    const int split = blockIdx.z, kh = blockIdx.x, b = blockIdx.y;   // `split` = chunk index
+    auto div_bs = [&](int x) { return p_bs_shift >= 0 ? x >> p_bs_shift : x / p_block_size; };
     const int NC = p_chunks;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -553,8 +557,8 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     const int wtok = wave * WT;
     int pass = split;
     int tok0 = pass * SPLIT + wtok;
-    int bid = load_uniform_i32(p_block_tables + bt_row + min(tok0 / p_block_size, p_max_blocks - 1));
-    int bid_next = load_uniform_i32(p_block_tables + bt_row + min((tok0 + NC * SPLIT) / p_block_size, p_max_blocks - 1));
+    int bid = load_uniform_i32(p_block_tables + bt_row + min(div_bs(tok0), p_max_blocks - 1));
+    int bid_next = load_uniform_i32(p_block_tables + bt_row + min(div_bs(tok0 + NC * SPLIT), p_max_blocks - 1));
     const int ctx = load_uniform_i32(p_context_lens + b);
     const int live_passes = (ctx + SPLIT - 1) / SPLIT;
     if (split >= live_passes) {
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     const int64_t row = (int64_t)p_kvh * D;                   // elements per token (all kv heads)
 
     auto issue_kv = [&](int t0, int block_id, int buf) {      // K then V image of the tile starting at token t0
-        const int off0 = t0 - (t0 / p_block_size) * p_block_size;
+        const int off0 = t0 - div_bs(t0) * p_block_size;
         const int64_t base = ((int64_t)block_id * p_block_size + off0) * row + (int64_t)kh * D;
         const int last = ctx - t0 - 1;                        // rows past the live range repeat the last live row
         unsigned char* const kimg = lds_w + buf * WAVE_BYTES;
@@ -623,7 +627,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             int bid_nn = 0;
             if (has_next) {
                 issue_kv(tok_next, bid_next, buf ^ 1);
-                bid_nn = load_uniform_i32(p_block_tables + bt_row + min((tok_next + NC * SPLIT) / p_block_size, p_max_blocks - 1));
+                bid_nn = load_uniform_i32(p_block_tables + bt_row + min(div_bs(tok_next + NC * SPLIT), p_max_blocks - 1));
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");      // q and this pass's K landed
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
@@ -942,16 +946,17 @@ int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
     // D = 64: 8 waves (two per SIMD, 32-token tiles) measured 8.5 % faster than 4 waves of 64-token tiles (ctx 1536: 11.0 ->
     // 10.05 us per call); NVH_DECODE_WAVES=4 selects the old shape for A/B.  D = 128 keeps 4 waves (its images are twice as large).
     static const int waves = [] { const char* e = getenv("NVH_DECODE_WAVES"); return e ? atoi(e) : 8; }();
-    dim3 grid(a.kvh * a.batch, a.chunks);
+    dim3 grid(a.kvh, a.batch, a.chunks);
+    const int bs_shift = (a.block_size & (a.block_size - 1)) == 0 ? __builtin_ctz(a.block_size) : -1;
     if constexpr (D == 64) {
         if (waves == 8) {
             hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
-                               a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, g, a);
+                               a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
             return check_launch("paged_decode_chunked");
         }
     }
     hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 4>), grid, dim3(4 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache, a.kvh,
-                       a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, g, a);
+                       a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
     return check_launch("paged_decode_chunked");
 }
 
