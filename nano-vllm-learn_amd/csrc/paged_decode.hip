@@ -581,24 +581,29 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     const int dp = lane % LPT, dr = lane / LPT;               // DMA: chunk position / row inside one instruction
     const int64_t row = (int64_t)p_kvh * D;                   // elements per token (all kv heads)
 
-    auto issue_kv = [&](int t0, int block_id, int buf) {      // K then V image of the tile starting at token t0
+    // K (which = 1), V (2) or both (3, K first) images of the tile starting at token t0
+    auto issue_kv = [&](int t0, int block_id, int buf, int which = 3) {
         const int off0 = t0 - div_bs(t0) * p_block_size;
         const int64_t base = ((int64_t)block_id * p_block_size + off0) * row + (int64_t)kh * D;
         const int last = ctx - t0 - 1;                        // rows past the live range repeat the last live row
         unsigned char* const kimg = lds_w + buf * WAVE_BYTES;
+        if (which & 1) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int T = i * TPI + dr;
-            const int Tc = T < last ? T : last;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_k_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
-                                             (__attribute__((address_space(3))) void*)(kimg + i * 1024), 16, 0, NVH_DMA_AUX);
+            for (int i = 0; i < NI; ++i) {
+                const int T = i * TPI + dr;
+                const int Tc = T < last ? T : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_k_cache + base + Tc * row + (dp ^ chunk_swizzle<LPT>(T)) * 8),
+                                                 (__attribute__((address_space(3))) void*)(kimg + i * 1024), 16, 0, NVH_DMA_AUX);
+            }
         }
+        if (which & 2) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int T = i * TPI + dr;
-            const int Tc = T < last ? T : last;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_v_cache + base + Tc * row + (dp ^ chunk_swizzle_v<LPT>(T)) * 8),
-                                             (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, NVH_DMA_AUX);
+            for (int i = 0; i < NI; ++i) {
+                const int T = i * TPI + dr;
+                const int Tc = T < last ? T : last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p_v_cache + base + Tc * row + (dp ^ chunk_swizzle_v<LPT>(T)) * 8),
+                                                 (__attribute__((address_space(3))) void*)(kimg + IMG + i * 1024), 16, 0, NVH_DMA_AUX);
+            }
         }
     };
 
@@ -608,6 +613,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
+        // first K image, then q, then the first V image: everything the K DMA needs arrived with the wave (preloaded arguments,
+        // the block id), while q's pointer is still behind a kernarg load; the first wait below (q and K landed) counts on q
+        // being older than V
+        issue_kv(tok0, bid, 0, 1);
         {
             const uint16_t* qp = a.q + (int64_t)b * a.q_row_stride + (int64_t)(kh * G) * D;
 #pragma unroll
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                                                  (__attribute__((address_space(3))) void*)(lds_q + i * 1024), 16, 0, 0);
             }
         }
-        issue_kv(tok0, bid, 0);
+        issue_kv(tok0, bid, 0, 2);
         NVH_STAMP(2);
         bf16x8 qf[STEPS];
         for (int buf = 0;; buf ^= 1) {

@@ -88,9 +88,10 @@ def test_paged_decode_golden(ops, golden, name):
         assert not o32[b].any() and not o16[b].any()
 
 
-def _decode_case(seed, B, H, KVH, D, ctx_lo, ctx_hi, width=None, pad=-1, bs=256):
+def _decode_case(seed, B, H, KVH, D, ctx_lo, ctx_hi, width=None, pad=-1, bs=256, force=()):
     rng = np.random.default_rng(seed)
     ctxs = rng.integers(ctx_lo, ctx_hi + 1, size=B)
+    ctxs[:len(force)] = force                                   # contexts the caller wants in the batch (boundaries)
     need = (ctxs + bs - 1) // bs
     nb = int(need.sum()) + 3
     width = width or int(need.max())
@@ -124,6 +125,21 @@ def test_paged_decode_vs_oracle(ops, B, H, KVH, D, lo, hi, width, pad):
     o16 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd)
     torch.cuda.synchronize()
     check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"decode B{B} H{H}/{KVH} D{D}")
+
+
+@pytest.mark.parametrize("bs", [64, 128, 192, 320, 512])
+def test_paged_decode_block_sizes(ops, bs):
+    """Block sizes other than the reference's 256 (any multiple of 64 is accepted): powers of two take the shift path of the
+    kernel's token -> block arithmetic, 192 and 320 the division path; contexts straddle block and pass boundaries."""
+    B, H, KVH, D = 7, 14, 2, 64
+    q, kc, vc, ctxs, bt = _decode_case(500 + bs, B, H, KVH, D, 1, 1400, bs=bs, force=[bs, bs + 1, 2 * bs - 1, min(3 * bs, 1400)])
+    exp = O.paged_decode(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), ctxs, bt)
+    qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
+    cl, btd = dev_i32(ctxs), dev_i32(bt)
+    o32 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, out_dtype=torch.float32)
+    o16 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd)
+    torch.cuda.synchronize()
+    check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"decode block_size {bs}")
 
 
 def test_decode_step_equals_store_then_decode(ops):
