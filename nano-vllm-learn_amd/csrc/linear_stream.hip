@@ -224,6 +224,17 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
         }
     }
     LS_STAMP(2);
+    // the epilogue's descriptor fields are fetched HERE, under the weight stream: left to the compiler their kernarg loads sit
+    // right in front of the first use (a scalar round trip in the tail of every launch)
+    void* const e_out = a.out;
+    uint16_t* const e_out_packed = a.out_packed;
+    const int64_t e_out_stride = a.out_stride;
+    float* const e_ws = a.ws;
+    unsigned* const e_counters = a.counters;
+    const float e_norm_eps = a.norm_eps;
+    uint16_t* const e_k_cache = a.k_cache;
+    uint16_t* const e_v_cache = a.v_cache;
+    asm volatile("" ::"s"(e_out), "s"(e_out_packed), "s"(e_out_stride), "s"(e_ws), "s"(e_counters), "s"(e_norm_eps), "s"(e_k_cache), "s"(e_v_cache));
 
     float ss2[MT];
 #pragma unroll
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
         }
         if (p_ksplit > 1) {
             // ---- split-K: publish the partial, take a ticket; the last arriver sums all partials in split order
-            float* const part = a.ws + ((int64_t)tile * p_ksplit + split) * PSTRIDE;
+            float* const part = e_ws + ((int64_t)tile * p_ksplit + split) * PSTRIDE;
 #pragma unroll
             for (int j = 0; j < EPT; ++j) {
                 if (tid + TPB * j < MT * 256) {                  // (8 waves, one row tile: the upper half of the threads owns no element)
@@ -333,14 +344,14 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(&a.counters[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned old = __hip_atomic_fetch_add(&e_counters[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (old == (unsigned)p_ksplit - 1)
-                    __hip_atomic_store(&a.counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+                    __hip_atomic_store(&e_counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
                 *lds_ticket = old;
             }
             __syncthreads();
             if (*lds_ticket != (unsigned)p_ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
-            const float* const base = a.ws + (int64_t)tile * p_ksplit * PSTRIDE;
+            const float* const base = e_ws + (int64_t)tile * p_ksplit * PSTRIDE;
             // partials are requested SB splits at a time, all loads of a batch in flight together; up to four splits (the
             // balanced down_proj shape) are one batch instead of an 8-wide one with half of it repeated
             auto sum_splits = [&](auto sb_tag) {
@@ -387,11 +398,11 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) y[nb] = s[j][nb];
             if constexpr (NORM == 2) {                                 // x.(g*W)^T * rsqrt(mean(x^2)+eps) == RMSNorm(x).W^T without the two bf16 roundings
-                const float inv_row = rsqrtf(rowss[j] / p_K + a.norm_eps);
+                const float inv_row = rsqrtf(rowss[j] / p_K + e_norm_eps);
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) y[nb] *= inv_row;
             }
-            __bf16* const out = reinterpret_cast<__bf16*>(a.out);
+            __bf16* const out = reinterpret_cast<__bf16*>(e_out);
             if constexpr (EPI == EPI_SILU && WIDE) {
 #pragma unroll
                 for (int hb = 0; hb < 2; ++hb) {                           // full block (16 columns), half block (8 columns)
@@ -399,20 +410,20 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
                     if ((hb == 1 && c >= 8) || col >= p_inter) continue;
                     const float g = (float)(__bf16)y[hb], u = (float)(__bf16)y[2 + hb];
                     const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
-                    if (out) out[(int64_t)row * a.out_stride + col] = o;
-                    if (a.out_packed) a.out_packed[pack_index(row, col, p_inter)] = __builtin_bit_cast(uint16_t, o);
+                    if (out) out[(int64_t)row * e_out_stride + col] = o;
+                    if (e_out_packed) e_out_packed[pack_index(row, col, p_inter)] = __builtin_bit_cast(uint16_t, o);
                 }
             } else if constexpr (EPI == EPI_SILU) {
                 const float g = (float)(__bf16)y[0], u = (float)(__bf16)y[1];          // the projection output is bf16 in the reference
                 const __bf16 o = (__bf16)((float)(__bf16)(g / (1.f + __expf(-g))) * u);
-                if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
-                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, p_inter)] = __builtin_bit_cast(uint16_t, o);
+                if (out) out[(int64_t)row * e_out_stride + n0 + c] = o;
+                if (e_out_packed) e_out_packed[pack_index(row, n0 + c, p_inter)] = __builtin_bit_cast(uint16_t, o);
             } else if constexpr (EPI == EPI_RESADD) {
-                __bf16* p = out + (int64_t)row * a.out_stride + n0 + c;
+                __bf16* p = out + (int64_t)row * e_out_stride + n0 + c;
                 const float old = MULTI ? (float)*p : (float)__builtin_bit_cast(__bf16, resid[j]);
                 const __bf16 o = (__bf16)(y[0] + old);
                 *p = o;
-                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
+                if (e_out_packed) e_out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
             } else if constexpr (EPI == EPI_ROPE) {
                 float x1 = y[0], x2 = y[1];
                 if (a.bias) {                                              // (x + 0.f would also be exact, but keep the no-bias path add-free)
@@ -430,14 +441,14 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
                     y2 = p3 + p4;
                 }
                 if (head < a.h) {
-                    __bf16* q = out + (int64_t)row * a.out_stride + head * p_hd + i;
+                    __bf16* q = out + (int64_t)row * e_out_stride + head * p_hd + i;
                     q[0] = (__bf16)y1;
                     q[p_hd / 2] = (__bf16)y2;
                 } else {
                     const int slot = rp_slot[j];
                     if (slot >= 0) {
                         const bool is_v = head >= a.h + a.kvh;
-                        __bf16* dst = reinterpret_cast<__bf16*>(is_v ? a.v_cache : a.k_cache) +
+                        __bf16* dst = reinterpret_cast<__bf16*>(is_v ? e_v_cache : e_k_cache) +
                                       ((int64_t)slot * a.kvh + (head - a.h - (is_v ? a.kvh : 0))) * p_hd + i;
                         dst[0] = (__bf16)y1;
                         dst[p_hd / 2] = (__bf16)y2;
@@ -445,8 +456,8 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
                 }
             } else {
                 const __bf16 o = (__bf16)(y[0] + (a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f));
-                if (out) out[(int64_t)row * a.out_stride + n0 + c] = o;
-                if (a.out_packed) a.out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
+                if (out) out[(int64_t)row * e_out_stride + n0 + c] = o;
+                if (e_out_packed) e_out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
                 if (a.cand_val && (float)o > best_v[j]) {                  // tiles ascend: a strict > keeps the lowest column
                     best_v[j] = (float)o;
                     best_i[j] = n0 + c;

@@ -612,6 +612,13 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // descriptor fields of the hand-off and the output, fetched under the first K/V images (pinned below): left to the compiler
+    // their kernarg loads sit in front of the first use, a scalar round trip each in the tail of the launch
+    float* const e_ws_acc = a.ws_acc;
+    unsigned* const e_counters = a.counters;
+    void* const e_out = a.out;
+    uint16_t* const e_out_packed = a.out_packed;
+    const int e_out_f32 = a.out_f32, e_h = a.h;
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
         // first K image, then q, then the first V image: everything the K DMA needs arrived with the wave (preloaded arguments,
         // the block id), while q's pointer is still behind a kernarg load; the first wait below (q and K landed) counts on q
@@ -629,6 +636,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         }
         issue_kv(tok0, bid, 0, 2);
         NVH_STAMP(2);
+        asm volatile("" ::"s"(e_ws_acc), "s"(e_counters), "s"(e_out), "s"(e_out_packed), "s"(e_out_f32), "s"(e_h));
         bf16x8 qf[STEPS];
         for (int buf = 0;; buf ^= 1) {
             const int tok_next = tok0 + NC * SPLIT;
@@ -792,7 +800,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     NVH_TSTAMP(1);
     if (live_chunks > 1) {
         const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
-        float* const recs = a.ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
+        float* const recs = e_ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
         float* const mine = recs + (int64_t)split * rec;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
@@ -810,7 +818,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         __syncthreads();
         NVH_TSTAMP(3);
         if (tid == 0) {
-            unsigned* const ctr = a.counters + (int64_t)b * p_kvh + kh;
+            unsigned* const ctr = e_counters + (int64_t)b * p_kvh + kh;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *lds_ticket = old;
@@ -867,10 +875,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         const int idx = tid + e * WAVES * 64;
         if (idx < G * D) {
             const float r = Ov[e] / Lv[e];
-            const int64_t oidx = ((int64_t)b * a.h + kh * G) * D + idx;
-            if (a.out_f32) reinterpret_cast<float*>(a.out)[oidx] = r;
-            else reinterpret_cast<__bf16*>(a.out)[oidx] = (__bf16)r;
-            if (a.out_packed) a.out_packed[pack_index(b, kh * G * D + idx, a.h * D)] = __builtin_bit_cast(uint16_t, (__bf16)r);
+            const int64_t oidx = ((int64_t)b * e_h + kh * G) * D + idx;
+            if (e_out_f32) reinterpret_cast<float*>(e_out)[oidx] = r;
+            else reinterpret_cast<__bf16*>(e_out)[oidx] = (__bf16)r;
+            if (e_out_packed) e_out_packed[pack_index(b, kh * G * D + idx, e_h * D)] = __builtin_bit_cast(uint16_t, (__bf16)r);
         }
     }
     NVH_STAMP(7);
