@@ -262,6 +262,16 @@ int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* can
                                   int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
                                   const int32_t* block_tables, int64_t bt_row_stride, int block_size,
                                   int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, void* stream);
+/* The same, and the NEXT step's token embedding in the same launch (VocabParallelEmbedding.forward at tp = 1,
+ * nanovllm/layers/embed_head.py:34-45): hidden_out[r, :] = embed_weight[input_ids[r], :] with the token just chosen (rows with
+ * context_lens 0 keep their token), and, if hidden_packed is not NULL, the same rows in fragment order for a following
+ * nvh_linear_small_m_ex with x_packed.  embed_weight [vocab, hidden] bf16 contiguous, hidden % 32 == 0, 16-byte aligned buffers. */
+int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
+                                        int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                                        const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                                        int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
+                                        const void* embed_weight, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
+                                        int dtype, void* stream);
 /* offset (in elements) of activation element (row, col) of an [m, cols] matrix in fragment order */
 int64_t nvh_pack_index(int row, int col, int cols);
 

@@ -408,10 +408,11 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
 size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue) { return linear_stream_workspace_bytes(m, n, k, epilogue); }
 int nvh_linear_small_m_candidate_groups(int n, int k) { return linear_stream_candidate_groups(n, k); }
 
-int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
+static int greedy_advance_candidates_impl(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
                                   int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
                                   const int32_t* block_tables, int64_t bt_row_stride, int block_size,
-                                  int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, void* stream) {
+                                  int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
+                                  const void* embed, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed, void* stream) {
     if (n_rows == 0) return 0;
     if (!candidate_val || !candidate_idx || !input_ids || !positions || !context_lens || !slot_mapping || !block_tables || !tokens_log || !row_steps) {
         set_error("greedy_advance_candidates: null pointer");
@@ -419,7 +420,40 @@ int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* can
     }
     if (n_rows < 0 || groups <= 0 || candidate_stride < n_rows || block_size <= 0 || log_row_stride < n_rows) { set_error("greedy_advance_candidates: bad shape"); return NVH_E_SHAPE; }
     AdvanceArgs adv{input_ids, positions, context_lens, slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps};
+    if (embed) {
+        if (!hidden_out) { set_error("greedy_advance_candidates_embed: null pointer"); return NVH_E_NULL; }
+        if (hidden <= 0 || hidden % 32 != 0 || hidden_row_stride < hidden || hidden_row_stride % 8 != 0) {
+            set_error("greedy_advance_candidates_embed: hidden=%d must be a multiple of 32, row stride %lld a multiple of 8 and >= hidden", hidden, (long long)hidden_row_stride);
+            return NVH_E_SHAPE;
+        }
+        if (!aligned16(embed) || !aligned16(hidden_out) || (hidden_packed && !aligned16(hidden_packed))) {
+            set_error("greedy_advance_candidates_embed: embed / hidden_out / hidden_packed must be 16-byte aligned");
+            return NVH_E_ALIGN;
+        }
+        adv.embed = (const uint16_t*)embed; adv.hidden = hidden; adv.hidden_out = (uint16_t*)hidden_out;
+        adv.hidden_stride = hidden_row_stride; adv.hidden_packed = (uint16_t*)hidden_packed;
+    }
     return launch_argmax_candidates(candidate_val, candidate_idx, groups, candidate_stride, n_rows, adv, (hipStream_t)stream);
+}
+int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
+                                  int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                                  const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                                  int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, void* stream) {
+    return greedy_advance_candidates_impl(candidate_val, candidate_idx, groups, candidate_stride, n_rows, input_ids, positions, context_lens,
+                                          slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps,
+                                          nullptr, 0, nullptr, 0, nullptr, stream);
+}
+int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
+                                        int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
+                                        const int32_t* block_tables, int64_t bt_row_stride, int block_size,
+                                        int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
+                                        const void* embed_weight, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
+                                        int dtype, void* stream) {
+    if (dtype != NVH_BF16) { set_error("greedy_advance_candidates_embed: dtype %d not supported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!embed_weight) { set_error("greedy_advance_candidates_embed: null pointer"); return NVH_E_NULL; }
+    return greedy_advance_candidates_impl(candidate_val, candidate_idx, groups, candidate_stride, n_rows, input_ids, positions, context_lens,
+                                          slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps,
+                                          embed_weight, hidden, hidden_out, hidden_row_stride, hidden_packed, stream);
 }
 int64_t nvh_pack_index(int row, int col, int cols) { return pack_index(row, col, cols); }
 

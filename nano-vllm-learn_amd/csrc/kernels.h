@@ -67,6 +67,13 @@ struct AdvanceArgs {             // all null: plain argmax
     int64_t* tokens_log;         // [steps, log_stride] generated tokens
     int64_t log_stride;
     int64_t* row_steps;          // [rows] tokens generated so far per row (log row index)
+    // next step's embedding lookup (candidates form only; all null: none): embed[input_ids[row]] -> hidden_out row and,
+    // if hidden_packed, the same row in fragment order (pack_index) for the first projection of the next step
+    const uint16_t* embed;       // [vocab, hidden] bf16
+    int hidden;
+    uint16_t* hidden_out;        // [rows, hidden], row stride hidden_stride
+    int64_t hidden_stride;
+    uint16_t* hidden_packed;     // nullable
 };
 int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, const AdvanceArgs& adv, hipStream_t stream);
 int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows,

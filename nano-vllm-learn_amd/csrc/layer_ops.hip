@@ -166,7 +166,19 @@ __global__ __launch_bounds__(256) void argmax_candidates_kernel(const float* __r
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
             if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+        if (adv.embed) lds_i[0] = adv.context_lens[row] > 0 ? bidx : (int)adv.input_ids[row];   // padding rows keep their token
         advance_row(adv, row, bidx);
+    }
+    if (adv.embed) {
+        // the next step's embedding lookup (layers/embed_head.py:34-45 at tp = 1) by the workgroup that has just chosen the token
+        __syncthreads();
+        const uint16_t* src = adv.embed + (int64_t)lds_i[0] * adv.hidden;
+        for (int c = threadIdx.x * 8; c < adv.hidden; c += 256 * 8) {        // hidden % 8 == 0 (host)
+            const u32x4 v = *reinterpret_cast<const u32x4*>(src + c);
+            *reinterpret_cast<u32x4*>(adv.hidden_out + (int64_t)row * adv.hidden_stride + c) = v;
+            // eight consecutive columns of one row are contiguous in fragment order as well
+            if (adv.hidden_packed) *reinterpret_cast<u32x4*>(adv.hidden_packed + pack_index(row, c, adv.hidden)) = v;
+        }
     }
 }
 

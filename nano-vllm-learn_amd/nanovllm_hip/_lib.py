@@ -64,6 +64,11 @@ _SIGS = {
     "nvh_greedy_advance_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int] +
                                       [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                                                 ctypes.c_void_p, ctypes.c_void_p]),
+    "nvh_greedy_advance_candidates_embed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int] +
+                                            [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
+                                                                      ctypes.c_void_p] +
+                                            [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                             ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -187,6 +187,14 @@ class DecodeSession:
         cfg = runner.cfg
         h = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, runner.world_size, runner.rank)[1]
         ops.reserve_workspace(dev, ops.decode_workspace_bytes(b, h, cfg.head_dim, self.block_tables.shape[1], bs))
+        # the next step's embedding lookup rides in the arg-max launch when the model allows it: the session then owns the
+        # embedded rows (row-major = the residual stream of the step, and in fragment order for layer 0's projection)
+        self.fuse_embed = bool(getattr(runner.model, "fused_embedding_ok", lambda *_: False)(b, torch.device(dev)))
+        if self.fuse_embed:
+            hid = cfg.hidden_size
+            self.hidden_in = torch.zeros(b, hid, dtype=torch.bfloat16, device=dev)
+            self.hidden_in_p = torch.zeros(((b + 15) // 16) * 16 * hid, dtype=torch.bfloat16, device=dev)
+            self._refresh_embedding()
         self.graph = None
         if use_graph and runner.world_size > 1 and dist.get_backend() != "nccl" and not os.environ.get("NVH_TRY_CAPTURE"):
             use_graph = False                                 # only RCCL collectives can be captured; anything else runs eager steps
@@ -212,15 +220,28 @@ class DecodeSession:
         blk = torch.gather(self.block_tables, 1, (last // bs).unsqueeze(1)).squeeze(1)
         self.slot_mapping.copy_((blk.long() * bs + last % bs).int())
 
+    @torch.inference_mode()
+    def _refresh_embedding(self):
+        """(Re)build the embedded rows from input_ids: at the start and whenever the metadata is set from outside."""
+        self.hidden_in.copy_(self.runner.model.embed_tokens(self.input_ids))
+        packed = ops.pack_rows(self.hidden_in)
+        self.hidden_in_p[: packed.numel()].copy_(packed)
+
     def _step(self):
         set_context(False, slot_mapping=self.slot_mapping, context_lens=self.context_lens, block_tables=self.block_tables)
-        hidden = self.runner.model(self.input_ids, self.positions)
-        cand = self.runner.model.greedy_candidates(hidden)     # LM head + arg-max candidates in one launch (fused decode path)
+        model = self.runner.model
+        if self.fuse_embed:
+            hidden = model(self.input_ids, self.positions, embedded=(self.hidden_in, self.hidden_in_p))
+        else:
+            hidden = model(self.input_ids, self.positions)
+        cand = model.greedy_candidates(hidden)                 # LM head + arg-max candidates in one launch (fused decode path)
         if cand is not None:
+            embed = (model.embed_tokens.weight, self.hidden_in, self.hidden_in_p) if self.fuse_embed else None
             ops.greedy_advance_candidates(cand[0], cand[1], cand[2], self.batch, self.input_ids, self.positions, self.context_lens,
-                                          self.slot_mapping, self.block_tables, self.runner.block_size, self.tokens, self.row_steps)
+                                          self.slot_mapping, self.block_tables, self.runner.block_size, self.tokens, self.row_steps, embed=embed)
             reset_context()
             return
+        assert not self.fuse_embed, "the fused embedding needs the candidates path"
         logits = self.runner.model.compute_logits(hidden)
         if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.stride(0) % 8 == 0:
             # sampling + postprocess + next step's prepare_decode in ONE launch (nvh_greedy_advance)
@@ -236,6 +257,8 @@ class DecodeSession:
     def _restore(self, saved):
         for t, s in zip(self._live(), saved):
             t.copy_(s)
+        if self.fuse_embed:
+            self._refresh_embedding()
 
     @torch.inference_mode()
     def _capture(self):
@@ -277,6 +300,8 @@ class DecodeSession:
         """Reset the device metadata to a saved state (benchmark use: time the same context window repeatedly)."""
         for t, s in zip((self.input_ids, self.positions, self.context_lens, self.slot_mapping, self.step_idx, self.row_steps), seqs_state):
             t.copy_(s)
+        if self.fuse_embed:
+            self._refresh_embedding()
         self.steps_done = int(self.row_steps.max().item())
 
     def state(self):

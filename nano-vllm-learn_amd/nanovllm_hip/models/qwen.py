@@ -269,7 +269,13 @@ class QwenForCausalLM(nn.Module):
         if not cfg.tie_word_embeddings:
             self.lm_head = nn.Linear(cfg.hidden_size, cfg.vocab_size, bias=False)
 
-    def forward(self, input_ids, positions):
+    def forward(self, input_ids, positions, embedded=None):
+        """embedded = (hidden [m, hidden], packed) — fused decode path only: the token embeddings already looked up by the
+        previous step's nvh_greedy_advance_candidates_embed, row-major (it becomes the residual stream, updated in place) and in
+        fragment order (what layer 0's projection reads); input_ids is then not touched."""
+        if embedded is not None:
+            assert _fused_decode_ok(self.cfg, embedded[0]) and self._fused_shapes_ok()
+            return self._forward_decode_fused(embedded[0], positions, packed0=embedded[1])
         h, residual = self.embed_tokens(input_ids), None
         if _fused_decode_ok(self.cfg, h) and self._fused_shapes_ok():
             return self._forward_decode_fused(h, positions)
@@ -322,7 +328,7 @@ class QwenForCausalLM(nn.Module):
                              ws=torch.zeros(need, dtype=torch.uint8, device=device))
         return bufs[key]
 
-    def _forward_decode_fused(self, residual, positions):
+    def _forward_decode_fused(self, residual, positions, packed0=None):
         """Decode step with 6 launches per layer (qkv, attention split + combine, o_proj, gate_up, down): the norms ride in the
         projections (folded weights + epilogue row scale), residual adds / SiLU*mul / RoPE+store are GEMM epilogues.
         `residual` is the running residual stream (the embedding output, updated in place); every GEMM that updates it also
@@ -338,7 +344,10 @@ class QwenForCausalLM(nn.Module):
         tp = _tp()[1]
         for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
-            x, xrows = (residual, None) if i == 0 else (resid_p, m)       # layer 0 reads the embedding rows as they are
+            if i == 0:                                                    # layer 0 reads the embedding rows as they are, or packed
+                x, xrows = (residual, None) if packed0 is None else (packed0, m)
+            else:
+                x, xrows = resid_p, m
             if a.qk_norm:
                 # Qwen3: the per-head q/k RMSNorm needs a whole head in one workgroup, so it cannot ride in the GEMM epilogue:
                 # plain projection, then (q/k-norm -> RoPE -> KV store) as the one nvh_rope_store launch (qwen3.py:108-116)
@@ -385,6 +394,12 @@ class QwenForCausalLM(nn.Module):
             return ops.fused_linear(packed, self._folded_weights()["head"], x_packed_rows=m, norm_folded=True, norm_eps=self.norm.eps,
                                     workspace=self._decode_buffers(m, hidden_states.device)["ws"])
         return linear(hidden_states, w)
+
+    def fused_embedding_ok(self, m, device):
+        """DecodeSession asks: may the next step's embedding lookup ride in the arg-max launch?  (single rank: the reference's
+        vocab-parallel embedding needs an all-reduce otherwise; and the fused decode layer must apply)"""
+        return (FUSED_DECODE and _tp()[1] == 1 and self.cfg.attn_backend == "hip" and device.type == "cuda" and m <= 64
+                and self.embed_tokens.weight.dtype == torch.bfloat16 and self.cfg.hidden_size % 32 == 0 and self._fused_shapes_ok())
 
     def greedy_candidates(self, hidden_states):
         """Fused decode path only: LM head + per-workgroup arg-max candidates in one launch, logits never written.  Returns

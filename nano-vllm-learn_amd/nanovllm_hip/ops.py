@@ -400,11 +400,25 @@ def linear_candidate_groups(n, k) -> int:
 
 
 def greedy_advance_candidates(cand_val, cand_idx, groups, n_rows, input_ids, positions, context_lens, slot_mapping, block_tables, block_size,
-                              tokens_log, row_steps):
-    """greedy_advance on the candidate records of fused_linear(candidates=...) instead of logits."""
+                              tokens_log, row_steps, embed=None):
+    """greedy_advance on the candidate records of fused_linear(candidates=...) instead of logits.
+    embed = (weight [vocab, hidden], hidden_out [n_rows, hidden], hidden_packed or None): the same launch also looks up the
+    chosen tokens' embedding rows for the next step (row-major and, optionally, in fragment order)."""
     _require_i32(context_lens=context_lens, slot_mapping=slot_mapping, block_tables=block_tables)
     for t in (input_ids, positions, tokens_log, row_steps):
         assert t.dtype == torch.int64 and t.is_cuda
+    if embed is not None:
+        w, hid, packed = embed
+        _require_gpu_bf16(embed_weight=w, hidden_out=hid)
+        assert w.is_contiguous() and hid.shape == (n_rows, w.shape[1]) and hid.stride(1) == 1
+        assert packed is None or (packed.dtype == torch.bfloat16 and packed.is_cuda and packed.numel() >= ((n_rows + 15) // 16) * 16 * w.shape[1])
+        rc = _lib.load().nvh_greedy_advance_candidates_embed(
+            cand_val.data_ptr(), cand_idx.data_ptr(), groups, cand_val.stride(0), n_rows, input_ids.data_ptr(), positions.data_ptr(),
+            context_lens.data_ptr(), slot_mapping.data_ptr(), block_tables.data_ptr(), block_tables.stride(0), block_size,
+            tokens_log.data_ptr(), tokens_log.stride(0), row_steps.data_ptr(), w.data_ptr(), w.shape[1], hid.data_ptr(), hid.stride(0),
+            None if packed is None else packed.data_ptr(), NVH_BF16, _stream())
+        _lib.check(rc, "nvh_greedy_advance_candidates_embed")
+        return
     rc = _lib.load().nvh_greedy_advance_candidates(cand_val.data_ptr(), cand_idx.data_ptr(), groups, cand_val.stride(0), n_rows,
                                                    input_ids.data_ptr(), positions.data_ptr(), context_lens.data_ptr(), slot_mapping.data_ptr(),
                                                    block_tables.data_ptr(), block_tables.stride(0), block_size, tokens_log.data_ptr(),

@@ -388,6 +388,21 @@ def test_stream_linear_greedy_candidates(m, n, k):
     assert torch.equal(ctxd.cpu()[live], ctx[live] + 1) and int(ctxd[0]) == 0 and int(ids[0]) == 0
     exp_slot = bt.cpu()[torch.arange(m), (ctx // bs).long()] * bs + ctx % bs
     assert torch.equal(slots.cpu()[live], exp_slot[live].int())
+    # the same launch with the next step's embedding lookup: identical bookkeeping, hidden rows = embed[token] (the padding row
+    # keeps the token it had), row-major and in fragment order
+    hid = 64 if n > 100000 else 96                             # small tables: [n, hid]
+    emb = torch.randn(n, hid, generator=g).bfloat16().cuda()
+    ids2 = torch.full((m,), 5, dtype=torch.int64, device="cuda")
+    pos2, ctx2, slots2 = ctx.long().cuda(), ctx.cuda(), torch.full((m,), -1, dtype=torch.int32, device="cuda")
+    log2, steps2 = torch.zeros(4, m, dtype=torch.int64, device="cuda"), torch.zeros(m, dtype=torch.int64, device="cuda")
+    hout = torch.full((m, hid), float("nan"), dtype=torch.bfloat16, device="cuda")
+    hpack = torch.zeros(((m + 15) // 16) * 16 * hid, dtype=torch.bfloat16, device="cuda")
+    ops.greedy_advance_candidates(cv2, ci2, groups, m, ids2, pos2, ctx2, slots2, bt, bs, log2, steps2, embed=(emb, hout, hpack))
+    torch.cuda.synchronize()
+    assert torch.equal(ids2.cpu()[live], ids.cpu()[live]) and int(ids2[0]) == 5 and torch.equal(ctx2, ctxd) and torch.equal(slots2, slots)
+    assert torch.equal(log2, log) and torch.equal(steps2, steps) and torch.equal(pos2.cpu()[live], pos.cpu()[live])
+    assert torch.equal(hout, emb[ids2])
+    assert torch.equal(hpack, ops.pack_rows(hout))
 
 
 @pytest.mark.parametrize("name", ["Qwen2-0.5B", "Qwen3-0.6B"])
