@@ -528,7 +528,9 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         }
     }
     static const int waves8 = [] { const char* e = getenv("NVH_GEMM_WAVES"); return e ? atoi(e) == 8 : 1; }();   // default 8; =4 for A/B
-    if (waves8) {
+    // (an LM head too deep for the multi-tile form, e.g. K = 3584: tens of thousands of workgroups, where four waves with four
+    // pieces each measured 262 us against 326 us for eight with two)
+    if (waves8 && !(EPI == EPI_NONE && a.tiles > 1024)) {
         hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, LS_FLAT(a));
         return check_launch("linear_stream");
     }

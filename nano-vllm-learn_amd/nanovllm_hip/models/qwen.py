@@ -398,8 +398,10 @@ class QwenForCausalLM(nn.Module):
     def fused_embedding_ok(self, m, device):
         """DecodeSession asks: may the next step's embedding lookup ride in the arg-max launch?  (single rank: the reference's
         vocab-parallel embedding needs an all-reduce otherwise; and the fused decode layer must apply)"""
+        from .. import ops
         return (FUSED_DECODE and _tp()[1] == 1 and self.cfg.attn_backend == "hip" and device.type == "cuda" and m <= 64
-                and self.embed_tokens.weight.dtype == torch.bfloat16 and self.cfg.hidden_size % 32 == 0 and self._fused_shapes_ok())
+                and self.embed_tokens.weight.dtype == torch.bfloat16 and self.cfg.hidden_size % 32 == 0 and self._fused_shapes_ok()
+                and ops.linear_candidate_groups(self.cfg.vocab_size, self.cfg.hidden_size) > 0)   # the arg-max must be the candidates launch
 
     def greedy_candidates(self, hidden_states):
         """Fused decode path only: LM head + per-workgroup arg-max candidates in one launch, logits never written.  Returns
