@@ -12,6 +12,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef short bf16x8_s __attribute__((ext_vector_type(8)));   // MFMA A/B fragment: 8 bf16 in 4 VGPRs

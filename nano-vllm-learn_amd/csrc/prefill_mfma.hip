@@ -93,6 +93,13 @@ __device__ __forceinline__ int chunk_swz_v(int row) {
     return LPT == 8 ? (row & 6) : ((2 * row) & 14);
 }
 
+// one v_cvt_pk_bf16_f32 (round to nearest even): {lo half = a, hi half = b}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int D, bool PAGED, int QT>
 __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a) {
     constexpr int BM = 64 * QT;                      // query rows per workgroup (4 waves x QT x 16)
@@ -280,14 +287,22 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 const float m_new = fmaxf(m_run[qs], mx);
                 // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;
-                float psum = 0.f;
+                // scale-and-subtract and the row sum on element PAIRS (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue slot;
+                // the loop is VALU-bound), exp2 per element
+                const f32x2 sc2 = {a.scale_log2, a.scale_log2}, mm2 = {-m_use, -m_use};
+                f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        sT[qs][tt][r] = fast_exp2(fmaf(sT[qs][tt][r], a.scale_log2, -m_use));   // one FMA: scale and subtract the max
-                        psum += sT[qs][tt][r];
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 sv = {sT[qs][tt][r], sT[qs][tt][r + 1]};
+                        const f32x2 z = __builtin_elementwise_fma(sv, sc2, mm2);
+                        const f32x2 e = {fast_exp2(z[0]), fast_exp2(z[1])};
+                        sT[qs][tt][r] = e[0];
+                        sT[qs][tt][r + 1] = e[1];
+                        psum2 += e;
                     }
+                const float psum = psum2[0] + psum2[1];
                 if (__builtin_amdgcn_ballot_w64(m_new != m_run[qs]) != 0) {      // some row's max moved: rescale (wave-uniform branch)
                     const float alpha = fast_exp2(m_run[qs] - m_use);            // m_run = -inf -> 0
                     l_run[qs] *= alpha;
@@ -302,13 +317,21 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
             for (int hh = 0; hh < BN / 32; ++hh) {
                 bf16x8 p_hi[QT], p_lo[QT];
 #pragma unroll
-                for (int qs = 0; qs < QT; ++qs)
+                for (int qs = 0; qs < QT; ++qs) {
+                    // five VALU instructions per element PAIR: pack hi, two unpacks, one packed (exact) subtract, pack lo
+                    u32x4 hraw, lraw;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const float pv = sT[qs][2 * hh + (i >> 2)][i & 3];
-                        p_hi[qs][i] = (__bf16)pv;
-                        p_lo[qs][i] = (__bf16)(pv - (float)p_hi[qs][i]);
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x2 pv = {sT[qs][2 * hh + (j >> 1)][2 * (j & 1)], sT[qs][2 * hh + (j >> 1)][2 * (j & 1) + 1]};
+                        const uint32_t hp = cvt_pk_bf16(pv[0], pv[1]);
+                        const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+                        const f32x2 lo = pv - hf;
+                        hraw[j] = hp;
+                        lraw[j] = cvt_pk_bf16(lo[0], lo[1]);
                     }
+                    p_hi[qs] = *reinterpret_cast<const bf16x8*>(&hraw);
+                    p_lo[qs] = *reinterpret_cast<const bf16x8*>(&lraw);
+                }
                 u32x2 vlo[DT], vhi[DT];
                 if (hh == 0) {
 #pragma unroll
