@@ -30,12 +30,17 @@ lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
 names = ["entry", "W DMA issued", "x loads issued", "all landed", "MFMAs done", "reduced / last arriver summed", "end"]
 ws = torch.zeros(4 << 20, dtype=torch.uint8, device=dev)
 
-def report(tag, nwg, waves=4):
+def report(tag, nwg=None, waves=8):
+    """Workgroups and waves are taken from the stamps themselves (a slot that was never written stays zero), so the report
+    follows whatever grid the launcher chose (wide tiles, balanced splits, 4 or 8 waves)."""
     torch.cuda.synchronize()
-    st = stamps.cpu().numpy()[: nwg * 64].reshape(nwg, 8, 8)[:, :waves, :7].astype(np.float64) * 0.01
+    st = stamps.cpu().numpy().reshape(-1, 8, 8)[:, :, :7].astype(np.float64) * 0.01
+    st = st[st[:, 0, 0] > 0]                                 # workgroups that ran
+    waves = int((st[0, :, 0] > 0).sum())
+    st = st[:, :waves, :]
     live = st[..., 6] > 0                                    # workgroups that were not the last arriver stop after stamp 4
     t0 = st[..., 0].min()
-    print(f"{tag}: {nwg} workgroups x {waves} waves; span (first entry -> last end) {st[..., 6].max() - t0:.2f} us")
+    print(f"{tag}: {st.shape[0]} workgroups x {waves} waves; span (first entry -> last end) {st[..., 6].max() - t0:.2f} us")
     for k, n in enumerate(names):
         sel = live if k >= 5 else np.ones_like(live)
         v = (st[..., k] - t0)[sel]
@@ -47,9 +52,12 @@ def report(tag, nwg, waves=4):
 
 def run(tag, nwg, fn, ws_list):
     for warm in (False, True):
-        stamps.zero_()
-        for l in range(2 * len(ws_list)):
+        n = 2 * len(ws_list)
+        for l in range(n - 1):
             fn(ws_list[0 if warm else l % len(ws_list)])
+        torch.cuda.synchronize()
+        stamps.zero_()                                         # the timeline of ONE call (the last arriver differs per call)
+        fn(ws_list[0 if warm else (n - 1) % len(ws_list)])
         report(tag + (" [warm: same weights every call]" if warm else " [cold: weights from HBM]"), nwg)
 
 from nanovllm_hip.models.qwen import cos_sin_table
