@@ -449,6 +449,7 @@ int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_
                                         int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
                                         const void* embed_weight, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
                                         int dtype, void* stream) {
+    if (n_rows == 0) return 0;
     if (dtype != NVH_BF16) { set_error("greedy_advance_candidates_embed: dtype %d not supported (bf16 only)", dtype); return NVH_E_DTYPE; }
     if (!embed_weight) { set_error("greedy_advance_candidates_embed: null pointer"); return NVH_E_NULL; }
     return greedy_advance_candidates_impl(candidate_val, candidate_idx, groups, candidate_stride, n_rows, input_ids, positions, context_lens,
