@@ -9,7 +9,9 @@ OUT = stamp_decode.OUT
 if not os.path.exists(OUT) or "--build" in sys.argv:
     stamp_decode.build()
 lib = ctypes.CDLL(OUT)
-B, S, H, KVH, D = 16, 1024, 14, 2, 64
+def _arg(name, default):
+    return int(sys.argv[sys.argv.index(name) + 1]) if name in sys.argv else default
+B, S, H, KVH, D = _arg("--batch", 16), _arg("--seq", 1024), 14, 2, 64
 T = B * S
 qkv = torch.randn(T, (H + 2 * KVH) * D, device="cuda", dtype=torch.bfloat16)
 q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KVH) * D], qkv[:, (H + KVH) * D:]
@@ -28,7 +30,7 @@ st = stamps.cpu().numpy().reshape(B, H, nq, 32).astype(np.float64) * 0.01
 t0 = st[..., 0].min()
 print(f"kernel span {st[..., 31].max() - t0:.1f} us; workgroup start: med {np.median(st[..., 0] - t0):.1f} max {(st[..., 0] - t0).max():.1f}")
 print(f"Q load wait: med {np.median(st[..., 1] - st[..., 0]):.2f} us")
-for qt in (0, 3, 15):
+for qt in sorted({0, min(3, nq - 1), nq - 1}):
     w = st[:, :, qt]
     n = qt + 1
     dma = [np.median(w[..., 2 + 3 * i] - (w[..., 1] if i == 0 else w[..., 4 + 3 * (i - 1)])) for i in range(min(n, 9))]
