@@ -398,6 +398,228 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     }
 }
 
+// ---- short sequences: every key of a sequence fits in LDS (sk <= 64 * NKT) ---------------------------------------------------
+// The tiled kernel above gives a (head, 64-row q-tile) to each workgroup: at S = 128 (BASELINE config 5) that is 3584 workgroups of
+// 3-7 us whose load -> compute phases run in lockstep, four per CU (census: tools/probes/stamp_prefill.py --batch 128 --seq 128), and
+// K / V are fetched 10x per kv head.  Here ONE workgroup per (sequence, kv head) stages the sequence's K / V images once (the same
+// swizzled images, all tiles resident), then its 8 waves stream the G query heads x 16-row sub-tiles through them: no barrier after
+// the staging one, the next task's Q rows are in flight while the current task computes, every HBM byte is read once.
+// Task t = (head g, sub-tile); the sub-tile index is rotated by g so that the causal triangle's light and heavy sub-tiles are
+// spread evenly over the waves.
+template <int D, int NKT, int NW>
+__global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArgs a) {
+    constexpr int ROWB = D * 2, LPT = D / 8, TPI = 64 / LPT, IMG = BN * ROWB, NI = IMG / 1024;
+    constexpr int STEPS = D / 32, DT = D / 16, NT = BN / 16;
+    static_assert((NKT - 1) * 2 * IMG + IMG + 48 * ROWB < 65536, "transposed V reads address tiles through the 16-bit ds offset");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NKT * 2 * IMG];   // [tile][K | V]
+
+    const int kh = blockIdx.x, b = blockIdx.y;
+    const int q_beg = a.cu_q[b], q_end = a.cu_q[b + 1];
+    const int k_beg = a.cu_k[b], k_end = a.cu_k[b + 1];
+    const int sq = q_end - q_beg, sk = k_end - k_beg;
+    if (sq <= 0 || sk <= 0) return;                  // whole workgroup, before the barrier
+    const int G = a.h / a.kvh;
+    const int shift = sk - sq;                       // bottom-right alignment: query r sees keys <= r + shift
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 15, lg = lane >> 4;
+    const int n_tiles = (sk + BN - 1) / BN;          // <= NKT (host)
+
+    // ---- stage every K / V tile of the sequence: DMA instruction `ins` = 1 KiB of one image, dealt round-robin to the waves
+    {
+        const int dp = lane % LPT, dr = lane / LPT;
+        for (int ins = wave; ins < n_tiles * NI; ins += NW) {                    // wave-uniform
+            const int tile = ins / NI, j = ins - tile * NI;
+            const int R = j * TPI + dr;                                          // row inside the tile
+            const int key = tile * BN + R;
+            const int kc = key < sk ? key : sk - 1;                              // rows past the end repeat the last key (masked)
+            const uint16_t* kp = a.k + (int64_t)(k_beg + kc) * a.k_row_stride + (int64_t)kh * D + (dp ^ chunk_swz<LPT>(R)) * 8;
+            const uint16_t* vp = a.v + (int64_t)(k_beg + kc) * a.v_row_stride + (int64_t)kh * D + (dp ^ chunk_swz_v<LPT>(R)) * 8;
+            unsigned char* const kimg = lds + tile * 2 * IMG + j * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)kp, (__attribute__((address_space(3))) void*)kimg, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vp, (__attribute__((address_space(3))) void*)(kimg + IMG), 16, 0, 0);
+        }
+    }
+
+    const int n_sub = (sq + 15) / 16, n_tasks = G * n_sub;
+    auto task_of = [&](int t, int& head, int& q0) {
+        const int g = t / n_sub;
+        int sub = t - g * n_sub + g;
+        sub -= (sub / n_sub) * n_sub;
+        head = kh * G + g;
+        q0 = 16 * sub;
+    };
+    // Q fragments of a task (B operand of S^T): Q[row][32 * step + 8 * lg .. + 8], plain loads to registers
+    auto load_q = [&](int t, bf16x8 (&qf)[STEPS]) {
+        int head, q0;
+        task_of(t, head, q0);
+        const int row = q0 + lq < sq ? q0 + lq : sq - 1;
+        const uint16_t* qp = a.q + (int64_t)(q_beg + row) * a.q_row_stride + (int64_t)head * D + lg * 8;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + st * 32);
+            qf[st] = *reinterpret_cast<const bf16x8*>(&raw);
+        }
+    };
+    bf16x8 qf[STEPS];
+    int t = wave;
+    if (t < n_tasks) load_q(t, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // this wave's share of the images (and its first Q)
+    __syncthreads();                                                             // everyone's: K / V are resident from here on
+
+    // transposed V reads: the per-lane part of the address is invariant; tile, image, 32-key half and the +16-row partner are
+    // immediates (see the tiled kernel)
+    const int vq = lq >> 2, vp = lq & 3;
+    uint32_t vaddr[DT];
+    {
+        const int R0 = 4 * lg + vq;
+        const int swz = chunk_swz_v<LPT>(R0);
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt) vaddr[tt] = lds_offset(lds + R0 * ROWB + (vp & 1) * 8 + (((2 * tt + (vp >> 1)) ^ swz) * 16));
+    }
+
+    for (; t < n_tasks; t += NW) {
+        bf16x8 qn[STEPS];
+        if (t + NW < n_tasks) load_q(t + NW, qn);                                // in flight while this task computes
+        int head, q0;
+        task_of(t, head, q0);
+        const int my_q = q0 + lq;
+        const int q_pos = my_q + shift;                                          // last key this lane's query may see
+        int last_key = q0 + 15 + shift;                                          // last key any row of the sub-tile may see
+        if (last_key > sk - 1) last_key = sk - 1;
+        const int n_t = last_key < 0 ? 0 : last_key / BN + 1;                    // wave-uniform
+
+        f32x4 o[DT];
+#pragma unroll
+        for (int tt = 0; tt < DT; ++tt) o[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float m_run = -INFINITY, l_run = 0.f;                                    // per query column; l_run is this lane group's share
+
+        auto tile = [&](auto itc) {
+            constexpr int it = decltype(itc)::value;
+            constexpr int KOFF = it * 2 * IMG, VOFF = KOFF + IMG;
+            const unsigned char* const kimg = lds + KOFF;
+            const int kv0 = it * BN;
+            f32x4 sT[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int R = 16 * tt + lq;
+#pragma unroll
+                for (int st = 0; st < STEPS; ++st) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + R * ROWB + (((4 * st + lg) ^ chunk_swz<LPT>(R)) * 16));
+                    sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
+                }
+            }
+            if (kv0 + BN - 1 > q0 + shift || kv0 + BN > sk) {                    // wave-uniform: the tile reaches the diagonal or the end
+#pragma unroll
+                for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kv0 + 16 * tt + 4 * lg + r;
+                        sT[tt][r] = (key <= q_pos && key < sk) ? sT[tt][r] : -INFINITY;
+                    }
+            }
+            float mx = max3(sT[0][0], sT[0][1], sT[0][2]);
+            mx = max3(mx, sT[0][3], sT[1][0]);
+            mx = max3(mx, sT[1][1], sT[1][2]);
+            mx = max3(mx, sT[1][3], sT[2][0]);
+            mx = max3(mx, sT[2][1], sT[2][2]);
+            mx = max3(mx, sT[2][3], sT[3][0]);
+            mx = max3(mx, sT[3][1], sT[3][2]);
+            mx = fmaxf(mx, sT[3][3]);
+            mx = max_xor16(mx);
+            mx = max_xor32(mx);
+            mx *= a.scale_log2;
+            const float m_new = fmaxf(m_run, mx);
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;                // rows that have seen no key yet
+            const f32x2 sc2 = {a.scale_log2, a.scale_log2}, mm2 = {-m_use, -m_use};
+            f32x2 psum2 = {0.f, 0.f};
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; r += 2) {
+                    const f32x2 sv = {sT[tt][r], sT[tt][r + 1]};
+                    const f32x2 z = __builtin_elementwise_fma(sv, sc2, mm2);
+                    const f32x2 e = {fast_exp2(z[0]), fast_exp2(z[1])};
+                    sT[tt][r] = e[0];
+                    sT[tt][r + 1] = e[1];
+                    psum2 += e;
+                }
+            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {              // some row's max moved: rescale (wave-uniform branch)
+                const float alpha = fast_exp2(m_run - m_use);                    // m_run = -inf -> 0
+                l_run *= alpha;
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) o[tt] *= alpha;
+            }
+            l_run += psum2[0] + psum2[1];
+            m_run = m_new;
+#pragma unroll
+            for (int hh = 0; hh < BN / 32; ++hh) {
+                u32x4 hraw, lraw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x2 pv = {sT[2 * hh + (j >> 1)][2 * (j & 1)], sT[2 * hh + (j >> 1)][2 * (j & 1) + 1]};
+                    const uint32_t hp = cvt_pk_bf16(pv[0], pv[1]);
+                    const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+                    const f32x2 lo = pv - hf;
+                    hraw[j] = hp;
+                    lraw[j] = cvt_pk_bf16(lo[0], lo[1]);
+                }
+                const bf16x8 p_hi = *reinterpret_cast<const bf16x8*>(&hraw), p_lo = *reinterpret_cast<const bf16x8*>(&lraw);
+                u32x2 vlo[DT], vhi[DT];
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) {
+                    if (hh == 0) {
+                        vlo[tt] = ds_read_tr16_b64_asm<VOFF>(vaddr[tt]);
+                        vhi[tt] = ds_read_tr16_b64_asm<VOFF + 16 * ROWB>(vaddr[tt]);
+                    } else {
+                        vlo[tt] = ds_read_tr16_b64_asm<VOFF + 32 * ROWB>(vaddr[tt]);
+                        vhi[tt] = ds_read_tr16_b64_asm<VOFF + 48 * ROWB>(vaddr[tt]);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8 vf[DT];
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) {
+                    const u32x4 raw = {vlo[tt][0], vlo[tt][1], vhi[tt][0], vhi[tt][1]};
+                    vf[tt] = *reinterpret_cast<const bf16x8*>(&raw);
+                }
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt], p_hi, o[tt], 0, 0, 0);
+#pragma unroll
+                for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt], p_lo, o[tt], 0, 0, 0);
+            }
+        };
+        if (0 < n_t) tile(std::integral_constant<int, 0>{});
+        if constexpr (NKT > 1) { if (1 < n_t) tile(std::integral_constant<int, 1>{}); }
+        if constexpr (NKT > 2) { if (2 < n_t) tile(std::integral_constant<int, 2>{}); }
+        if constexpr (NKT > 3) { if (3 < n_t) tile(std::integral_constant<int, 3>{}); }
+
+        // ---- finalise the task: total row sum over the 4 lane groups, normalise, store 4 contiguous dims per tile
+        float l = sum_xor16(l_run);
+        l = sum_xor32(l);
+        if (my_q < sq) {
+            const float inv = l > 0.f ? 1.f / l : 0.f;
+            const int64_t orow = ((int64_t)(q_beg + my_q) * a.h + head) * D;
+#pragma unroll
+            for (int tt = 0; tt < DT; ++tt) {
+                const int d0 = 16 * tt + 4 * lg;
+                const f32x4 r = o[tt] * inv;
+                if (a.out_f32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.out) + orow + d0) = r;
+                } else {
+                    u32x2 pk = {pack_bf16x2(r[0], r[1]), pack_bf16x2(r[2], r[3])};
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + orow + d0) = pk;
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) qf[st] = qn[st];
+    }
+}
+
 template <int D, int QT>
 int launch_q(const PrefillArgs& a, hipStream_t stream) {
     dim3 grid(a.h, a.batch, (a.max_seqlen_q + 64 * QT - 1) / (64 * QT));
@@ -406,8 +628,37 @@ int launch_q(const PrefillArgs& a, hipStream_t stream) {
     return check_launch("prefill_varlen");
 }
 
+// NVH_PREFILL_SHORT: 0 = never, 2 = whenever the shape allows (tests), default = when it also fills the chip
+template <int D>
+int launch_short(const PrefillArgs& a, hipStream_t stream, bool& taken) {
+    taken = false;
+    const char* e = getenv("NVH_PREFILL_SHORT");
+    const int mode = e ? atoi(e) : 1;
+    const int max_keys = 128;                                    // (256 keys with four resident tiles measured slower than the tiled kernel)
+    if (mode == 0 || a.block_tables || a.max_seqlen_k > max_keys || a.max_seqlen_q > a.max_seqlen_k) return 0;
+    if (mode != 2 && a.batch * a.kvh < 128) return 0;            // few sequences: the tiled kernel spreads heads and q-tiles over the CUs
+    taken = true;
+    dim3 grid(a.kvh, a.batch);
+    // a wave's tile is a long dependent chain (QK -> max -> exp2 -> hi/lo -> PV): four waves per SIMD to fill it where the registers allow
+    // (measured, Qwen2-0.5B heads, S = 128: 256 workgroups 22.7 us with 16 waves against 25.2 with 8; 512 workgroups, two per CU,
+    // 37.4 us with 8 against 41.9 with 16; the tiled kernel 28.3 / 56)
+    const char* w = getenv("NVH_PREFILL_SHORT_WAVES");           // A/B knob
+    const int waves = w ? atoi(w) : (a.batch * a.kvh >= 384 ? 8 : 16);
+    if constexpr (D == 64) {
+        if (waves == 16) {
+            hipLaunchKernelGGL((prefill_short_kernel<D, 2, 16>), grid, dim3(1024), 0, stream, a);
+            return check_launch("prefill_short");
+        }
+    }
+    hipLaunchKernelGGL((prefill_short_kernel<D, 2, 8>), grid, dim3(512), 0, stream, a);
+    return check_launch("prefill_short");
+}
+
 template <int D>
 int launch_d(const PrefillArgs& a, hipStream_t stream) {
+    bool taken;
+    const int rc = launch_short<D>(a, stream, taken);
+    if (taken) return rc;
     const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= 2048;
     return two ? launch_q<D, 2>(a, stream) : launch_q<D, 1>(a, stream);
 }

@@ -530,3 +530,42 @@ def test_prefill_randomised_varlen(seed):
     o16 = ops.flash_attn_varlen_func(qd, kd, vd, max(lens), cud, max(lens), cud)
     torch.cuda.synchronize()
     check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"prefill seed {seed} H{H}/{KVH} D{D} lens {lens}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_prefill_short_sequence_kernel(seed, monkeypatch):
+    """The resident-K/V kernel for short sequences (one workgroup per (sequence, kv head), NVH_PREFILL_SHORT=2 forces it on
+    any batch size) against the oracle and against the tiled kernel: lengths on the 16-row sub-tile and 64-key tile
+    boundaries, up to 128 keys, G in 1..8, strided views, and queries that are a suffix of
+    the keys (bottom-right causal alignment)."""
+    from nanovllm_hip import ops
+    rng = np.random.default_rng(5000 + seed)
+    D = int(rng.choice([64, 128]))
+    KVH = int(rng.choice([1, 2, 4]))
+    G = int(rng.choice([1, 2, 7, 8]))
+    H = KVH * G
+    cap = 128
+    pool = [x for x in [1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 191, 192, 193, 255, 256] if x <= cap]
+    klens = [int(x) for x in rng.choice(pool, size=int(rng.integers(1, 6)))]
+    suffix = seed % 3 == 2                                       # queries = the last sq rows of each sequence
+    qlens = [int(rng.integers(1, kl + 1)) for kl in klens] if suffix else list(klens)
+    Tq, Tk = sum(qlens), sum(klens)
+    gen = torch.Generator().manual_seed(6000 + seed)
+    kv = torch.randn(Tk, 2 * KVH * D, generator=gen).bfloat16()
+    qq = torch.randn(Tq, H * D + 8, generator=gen).bfloat16()
+    cuq = np.concatenate([[0], np.cumsum(qlens)]).astype(np.int32)
+    cuk = np.concatenate([[0], np.cumsum(klens)]).astype(np.int32)
+    exp = O.prefill_varlen(qq[:, :H * D].view(Tq, H, D).float().numpy(), kv[:, :KVH * D].view(Tk, KVH, D).float().numpy(),
+                           kv[:, KVH * D:].view(Tk, KVH, D).float().numpy(), cuq, cuk)
+    kvd, qqd = kv.cuda(), qq.cuda()
+    qd, kd, vd = qqd[:, :H * D].view(Tq, H, D), kvd[:, :KVH * D].view(Tk, KVH, D), kvd[:, KVH * D:].view(Tk, KVH, D)
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("NVH_PREFILL_SHORT", mode)
+        o32 = ops.flash_attn_varlen_func(qd, kd, vd, max(qlens), dev_i32(cuq), max(klens), dev_i32(cuk), out_dtype=torch.float32)
+        o16 = ops.flash_attn_varlen_func(qd, kd, vd, max(qlens), dev_i32(cuq), max(klens), dev_i32(cuk))
+        torch.cuda.synchronize()
+        check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"short prefill mode {mode} seed {seed} H{H}/{KVH} D{D} q{qlens} k{klens}")
+        outs[mode] = o32
+    assert (outs["2"] - outs["0"]).abs().max().item() <= 2e-4    # same arithmetic per (row, key tile); only the tile schedule differs
