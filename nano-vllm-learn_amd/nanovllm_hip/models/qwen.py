@@ -211,7 +211,11 @@ class QwenMLP(nn.Module):
         super().__init__()
         _, tp = _tp()
         assert cfg.intermediate_size % tp == 0
-        inter = cfg.intermediate_size // tp
+        self.inter = cfg.intermediate_size // tp
+        # a shard that is not a multiple of 64 columns (Qwen2-0.5B at tp = 8: 608) is padded with zero weights to the next one:
+        # SiLU(0) * 0 = 0 meets zero down_proj columns, the result is unchanged, and the streaming GEMMs (whole 128-byte weight
+        # lines per K piece) and with them the fused decode layer apply to every rank count
+        inter = self.inter if tp == 1 else (self.inter + 63) // 64 * 64
         self.gate_up_proj = nn.Linear(cfg.hidden_size, 2 * inter, bias=False)
         self.down_proj = nn.Linear(inter, cfg.hidden_size, bias=False)
 
@@ -286,7 +290,7 @@ class QwenForCausalLM(nn.Module):
 
     def _fused_shapes_ok(self):
         """Every contraction length of this rank's projections must be a multiple of 64 (one 128-byte line per weight row per
-        DMA piece of the streaming GEMM); Qwen2-0.5B at tp=8 has a 608-wide MLP shard and stays on the plain layer."""
+        DMA piece of the streaming GEMM); QwenMLP pads its shard to that (Qwen2-0.5B at tp=8: 608 -> 640 columns)."""
         a, mlp = self.layers[0].self_attn, self.layers[0].mlp
         return self.cfg.hidden_size % 64 == 0 and a.q_size % 64 == 0 and mlp.down_proj.weight.shape[1] % 64 == 0
 
@@ -436,9 +440,6 @@ class QwenForCausalLM(nn.Module):
         def draw(*shape):
             return torch.randn(*shape, generator=gen) * 0.02
 
-        def shard_rows(full, parts):                               # column-parallel: split output rows per part
-            return torch.cat([p.chunk(tp, dim=0)[rank] for p in parts(full)], dim=0)
-
         q0, qn, kv0, kvn = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
 
         def shard_qkv(full):                                       # rows of this rank's q heads | kv heads | kv heads
@@ -455,6 +456,8 @@ class QwenForCausalLM(nn.Module):
             if cfg.qkv_bias:
                 a.qkv_proj.bias.copy_(shard_qkv(draw(hq + 2 * hkv)))
             a.o_proj.weight.copy_(draw(cfg.hidden_size, hq)[:, q0 * d:(q0 + qn) * d])
-            m.gate_up_proj.weight.copy_(shard_rows(draw(2 * cfg.intermediate_size, cfg.hidden_size), lambda w: w.chunk(2, dim=0)))
-            m.down_proj.weight.copy_(draw(cfg.hidden_size, cfg.intermediate_size).chunk(tp, dim=1)[rank])
+            pad = m.down_proj.weight.shape[1] - m.inter                   # zero rows / columns of a padded shard (QwenMLP)
+            gate_up = [F.pad(p.chunk(tp, dim=0)[rank], (0, 0, 0, pad)) for p in draw(2 * cfg.intermediate_size, cfg.hidden_size).chunk(2, dim=0)]
+            m.gate_up_proj.weight.copy_(torch.cat(gate_up, dim=0))
+            m.down_proj.weight.copy_(F.pad(draw(cfg.hidden_size, cfg.intermediate_size).chunk(tp, dim=1)[rank], (0, pad)))
         return self

@@ -48,4 +48,36 @@ for tp in (2, 4, 8):
         print(f"tp={tp} rank {rank}: heads (q_start, q_count, kv_start, kv_count) = {part}; fused layer {fused}; graph replay ok", flush=True)
         del sess, eng
         torch.cuda.empty_cache()
+# fused vs plain decode layer on the same (stubbed) shard: the zero-padded MLP shard of tp = 8 goes through the streaming GEMMs
+from nanovllm_hip.engine.model_runner import build_decode_meta
+from nanovllm_hip.models import qwen
+from nanovllm_hip.utils.context import reset_context, set_context
+for tp, rank in ((8, 0), (8, 3), (4, 1)):
+    cfg = model_config(name, num_hidden_layers=2, vocab_size=4096)
+    try:
+        tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
+    except AssertionError:
+        continue
+    state.update(rank=rank, tp=tp)
+    out = {}
+    for fused in (True, False):
+        qwen.FUSED_DECODE = fused
+        eng = LLMEngine(cfg, num_kvcache_blocks=16, enforce_eager=True, seed=3)
+        gg = torch.Generator().manual_seed(7)
+        seqs = [Sequence(torch.randint(0, 4096, (n,), generator=gg).tolist(), max_tokens=4) for n in (300, 17, 256, 5, 129)]
+        eng.prefill(seqs, reserve_tokens=4)
+        r = eng.runner
+        m = build_decode_meta(seqs, r.block_size)
+        with torch.inference_mode():
+            set_context(False, slot_mapping=r._dev(m["slot_mapping"]), context_lens=r._dev(m["context_lens"]), block_tables=r._dev(m["block_tables"]))
+            hidden = r.model(r._dev(m["input_ids"]), r._dev(m["positions"]))
+            if fused:
+                assert getattr(r.model, "_pending_final_norm", None) is not None, "the fused layer was expected to run"
+            out[fused] = r.model.compute_logits(hidden).float().cpu()
+            reset_context()
+    qwen.FUSED_DECODE = True
+    a, b = out[True], out[False]
+    print(f"tp={tp} rank {rank}: MLP shard {eng.runner.model.layers[0].mlp.inter} -> {eng.runner.model.layers[0].mlp.down_proj.weight.shape[1]} columns; "
+          f"fused vs plain logits max abs diff {float((a - b).abs().max()):.4f} (scale {float(b.abs().max()):.2f})", flush=True)
+    assert (a - b).abs().max() <= 0.03 * b.abs().max()
 print("all rank shapes ok")
