@@ -73,9 +73,10 @@ TINY = dict(num_hidden_layers=2, hidden_size=128, head_dim=32, intermediate_size
             qkv_bias=True, qk_norm=False, max_position_embeddings=512)
 
 
-@pytest.mark.parametrize("world,heads,kv_heads,qk_norm", [(2, 4, 2, False), (4, 6, 2, False), (2, 4, 2, True)])
-def test_tp_equals_single_process(world, heads, kv_heads, qk_norm):
-    cfg_kwargs = dict(TINY, num_attention_heads=heads, num_key_value_heads=kv_heads, qk_norm=qk_norm)
+@pytest.mark.parametrize("world,heads,kv_heads,qk_norm,inter", [(2, 4, 2, False, 256), (4, 6, 2, False, 256), (2, 4, 2, True, 256),
+                                                                (4, 6, 2, False, 320)])   # 320 / 4 = 80-wide MLP shards, zero-padded to 128
+def test_tp_equals_single_process(world, heads, kv_heads, qk_norm, inter):
+    cfg_kwargs = dict(TINY, num_attention_heads=heads, num_key_value_heads=kv_heads, qk_norm=qk_norm, intermediate_size=inter)
     lens = [9, 1, 20]
     ref = _model_out(cfg_kwargs, lens).numpy()                      # single process (no process group): tp = 1
     mgr = mp.Manager()
