@@ -128,7 +128,7 @@ def cpu_baseline_leg(cfg, batch, ctx, budget_s=12.0):
         flash_attn_with_kvcache_cpu(q, kc, vc, cl, bt)
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 40:
+        if el >= budget_s or reps >= 96:            # ~10-15 s of host work: four decode steps' worth of layer calls at most
             break
     per_call = el / reps
     layers = cfg.num_hidden_layers
