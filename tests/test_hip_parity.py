@@ -264,6 +264,58 @@ def test_paged_prefill_prefix_cache_vs_oracle(ops):
     check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, "paged prefill")
 
 
+def test_chunked_prefill_equals_one_shot(ops):
+    """SURVEY §8f row 4 (chunked prefill): a prompt prefilled in chunks — each chunk's K/V stored into the paged cache
+    (store_kvcache), its queries attending to the cache so far (paged prefill, Sq < Sk, bottom-right causal mask) — gives the
+    rows of the one-shot varlen prefill of the whole prompt.  Same arithmetic per (row, 64-key tile) in the same key order, so
+    the fp32 outputs agree to accumulation-order noise, far inside the parity bar."""
+    H, KVH, D, bs = 14, 2, 64, 256
+    lens = [700, 130, 513]
+    chunks = [256, 200, 300]                                     # chunk sizes cycle; boundaries fall inside blocks and tiles
+    gen = torch.Generator().manual_seed(21)
+    T = sum(lens)
+    q = torch.randn(T, H, D, generator=gen).bfloat16().cuda()
+    k = torch.randn(T, KVH, D, generator=gen).bfloat16().cuda()
+    v = torch.randn(T, KVH, D, generator=gen).bfloat16().cuda()
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    ref = ops.flash_attn_varlen_func(q, k, v, max(lens), dev_i32(cu), max(lens), dev_i32(cu), out_dtype=torch.float32)
+    need = [(n + bs - 1) // bs for n in lens]
+    nb = sum(need) + 1
+    rng = np.random.default_rng(22)
+    ids = iter(rng.permutation(nb).tolist())
+    bt = np.full((len(lens), max(need)), -1, np.int32)
+    for i, n in enumerate(need):
+        for j in range(n):
+            bt[i, j] = next(ids)
+    kc = torch.zeros(nb, bs, KVH, D, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    out = torch.zeros_like(ref)
+    done = [0] * len(lens)
+    step = 0
+    while any(d < n for d, n in zip(done, lens)):
+        rows, slots, sq, sk, live = [], [], [], [], []
+        for i, n in enumerate(lens):                             # one scheduler step: the next chunk of every unfinished prompt
+            if done[i] >= n:
+                continue
+            c = min(chunks[(step + i) % len(chunks)], n - done[i])
+            tok = np.arange(done[i], done[i] + c)
+            rows.append(cu[i] + tok)
+            slots.append(bt[i, tok // bs] * bs + tok % bs)
+            sq.append(c); sk.append(done[i] + c); live.append(i)
+            done[i] += c
+        rows = torch.from_numpy(np.concatenate(rows)).cuda()
+        ops.store_kvcache(k[rows], v[rows], kc, vc, dev_i32(np.concatenate(slots)))
+        cu_q = np.concatenate([[0], np.cumsum(sq)]).astype(np.int32)
+        cu_k = np.concatenate([[0], np.cumsum(sk)]).astype(np.int32)
+        o = ops.flash_attn_varlen_func(q[rows].contiguous(), kc, vc, max(sq), dev_i32(cu_q), max(sk), dev_i32(cu_k),
+                                       block_table=dev_i32(bt[live]), out_dtype=torch.float32)
+        out[rows] = o
+        step += 1
+    torch.cuda.synchronize()
+    assert step >= 3
+    assert (out - ref).abs().max().item() <= 2e-4
+
+
 # ------------------------------------------------------------------------------------------ module
 def test_attention_module_prefill_then_decode(ops):
     """Attention.forward through the global Context, as Qwen3Attention.forward drives it (qwen3.py:117):
