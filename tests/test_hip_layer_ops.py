@@ -52,9 +52,12 @@ def test_silu_mul(rows, inter):
     close_bf16(out, ref, frac=0.05)
 
 
-def test_engine_greedy_tokens_graph_equals_eager():
-    """End to end through the engine: prefill + 12 decode steps of a 2-layer Qwen2-shaped model; the device-resident
-    HIP-graph session must produce exactly the tokens of the eager, host-metadata path (model_runner.py:278-303)."""
+@pytest.mark.parametrize("max_tokens", [13, 270])
+def test_engine_greedy_tokens_graph_equals_eager(max_tokens):
+    """End to end through the engine: prefill + decode steps of a 2-layer Qwen2-shaped model; the device-resident
+    HIP-graph session (metadata advanced on the device, next step's embedding looked up by the arg-max launch) must produce
+    exactly the tokens of the eager, host-metadata path (model_runner.py:278-303).  270 steps carry every sequence across a
+    block boundary (slot arithmetic of the device-side advance) and through hundreds of ticket resets."""
     from nanovllm_hip.engine.llm_engine import LLMEngine
     from nanovllm_hip.models.qwen import model_config
     cfg = model_config("Qwen2-0.5B", num_hidden_layers=2, vocab_size=2048)
@@ -63,9 +66,9 @@ def test_engine_greedy_tokens_graph_equals_eager():
     outs = []
     for eager in (True, False):
         eng = LLMEngine(cfg, num_kvcache_blocks=16, enforce_eager=eager, seed=1)
-        outs.append(eng.generate(prompts, max_tokens=13))
+        outs.append(eng.generate(prompts, max_tokens=max_tokens))
     assert outs[0] == outs[1]
-    assert all(len(o) == 13 for o in outs[0])
+    assert all(len(o) == max_tokens for o in outs[0])
 
 
 @pytest.mark.parametrize("m,n,k,bias", [(32, 1152, 896, True), (32, 896, 896, False), (32, 896, 4864, False), (1, 1024, 1024, False),
