@@ -115,6 +115,8 @@ def _decode_case(seed, B, H, KVH, D, ctx_lo, ctx_hi, width=None, pad=-1, bs=256,
     (4, 16, 8, 128, 250, 530, None, -1),        # Qwen3-0.6B (the reference's default model)
     (3, 8, 1, 64, 60, 70, None, -1),            # G = 8
     (3, 3, 3, 64, 255, 258, None, -1),          # G = 1 (MHA)
+    (2, 16, 1, 64, 100, 600, None, -1),         # G = 16: the whole MFMA tile width is live heads
+    (300, 16, 8, 128, 1, 300, None, 0),         # 2400 (sequence, kv head) pairs: one chunk each, no hand-off, a grid of many workgroups
 ])
 def test_paged_decode_vs_oracle(ops, B, H, KVH, D, lo, hi, width, pad):
     q, kc, vc, ctxs, bt = _decode_case(100 + B + H, B, H, KVH, D, lo, hi, width, pad)
