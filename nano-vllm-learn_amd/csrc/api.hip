@@ -145,7 +145,11 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
     a.batch = batch; a.h = h; a.kvh = kvh; a.hd = hd;
     a.block_size = block_size; a.max_blocks = max_blocks;
     a.num_splits = decode_num_splits(hd, max_blocks, block_size);
-    if ((size_t)batch * kvh * 4 > kDecodeTicketBytes) { set_error("paged_decode: batch * kvh = %d > %zu tickets", batch * kvh, kDecodeTicketBytes / 4); return NVH_E_SHAPE; }
+    // (tickets are only drawn when a (sequence, kv head) pair is split over several workgroups, i.e. when batch * kvh is small)
+    if (decode_chunks(batch, kvh, a.num_splits) > 1 && (size_t)batch * kvh * 4 > kDecodeTicketBytes) {
+        set_error("paged_decode: batch * kvh = %d > %zu tickets", batch * kvh, kDecodeTicketBytes / 4);
+        return NVH_E_SHAPE;
+    }
     a.counters = reinterpret_cast<unsigned*>(workspace);
     a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeTicketBytes);
     a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;
