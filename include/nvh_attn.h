@@ -94,6 +94,23 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
                      int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The same call through a chosen formulation of the decode kernel (tests and A/B measurements; nvh_paged_decode always runs
+ * NVH_DECODE_CHUNKED with waves = chunks = 0).  All variants compute the same function and are held to the same parity bar:
+ *   NVH_DECODE_CHUNKED     one launch: MFMA tiles over the GQA group, split-KV passes dealt to `chunks` workgroups per
+ *                          (sequence, kv head), last-arriver combine.  waves: 0 / 8 = eight waves per workgroup at hd 64, 4 = four.
+ *                          chunks: 0 = one wave of workgroups over the device's CUs, > 0 = that many (clamped to the passes).
+ *   NVH_DECODE_SPLIT_MFMA  the single-pass MFMA split kernel + a combine launch (flash-decoding in two launches).
+ *   NVH_DECODE_SPLIT_VALU  north_star's literal form: VALU dot products with wavefront-level (DPP / permlane) max and sum
+ *                          reductions, no MFMA; groups of at most 8 query heads per kv head; + the combine launch.
+ */
+enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2 };
+int nvh_paged_decode_variant(int variant, int waves, int chunks, void* out, const void* q, const void* k_cache, const void* v_cache,
+                             const int32_t* block_tables, const int32_t* context_lens,
+                             int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                             int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * nvh_paged_decode that ALSO writes the bf16 result in MFMA-fragment order (out_packed: [ceil(batch/16)][h*hd/32][64][8],
  * nvh_pack_index(row = sequence, col = head*hd + dim, cols = h*hd)) for a following nvh_linear_small_m_ex with x_packed = 1
  * (the output projection, models/qwen3.py:118).  Same arguments otherwise; `out` is still written.
@@ -131,6 +148,9 @@ int nvh_decode_step(void* out, const void* q, const void* k_new, const void* v_n
  *                  model_runner.py:204-207).  The causal mask is bottom-right aligned: query row r
  *                  of a sequence sees keys 0 .. r + (Sk - Sq)  (flash-attn semantics; equals the
  *                  oracle's top-left mask whenever Sq == Sk).
+ *                  CONTRACT: max_seqlen_q / max_seqlen_k must bound every sequence in cu_seqlens_q/k (as the reference's
+ *                  runner guarantees).  The library cannot check device data without a host sync; rows / keys beyond an
+ *                  understated maximum are not processed (never an out-of-bounds access).
  *   out            [total_q, h, hd] contiguous, out_dtype NVH_BF16 or NVH_F32.
  */
 int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
@@ -139,6 +159,21 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
                        int h, int kvh, int hd, int block_size, int max_blocks,
                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                        int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream);
+
+/*
+ * The same call with the kernel chosen by the caller (tests and A/B measurements; nvh_prefill_varlen passes 0, 0):
+ *   kernel       NVH_PREFILL_AUTO, NVH_PREFILL_TILED (64-row query tiles, K/V tiles double-buffered through LDS) or
+ *                NVH_PREFILL_SHORT (one workgroup per (sequence, kv head), K/V resident in LDS: needs max_seqlen_q <=
+ *                max_seqlen_k <= 128 and block_tables == NULL, otherwise an error)
+ *   short_waves  waves per workgroup of the short-sequence kernel: 0 = auto, 8 or 16
+ */
+enum { NVH_PREFILL_AUTO = 0, NVH_PREFILL_TILED = 1, NVH_PREFILL_SHORT = 2 };
+int nvh_prefill_varlen_variant(int kernel, int short_waves, void* out, const void* q, const void* k, const void* v,
+                               const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                               const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
+                               int h, int kvh, int hd, int block_size, int max_blocks,
+                               int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                               int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream);
 
 /*
  * "Next" row: the step immediately before attention, fused into one launch.
@@ -265,12 +300,14 @@ int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* can
 /* The same, and the NEXT step's token embedding in the same launch (VocabParallelEmbedding.forward at tp = 1,
  * nanovllm/layers/embed_head.py:34-45): hidden_out[r, :] = embed_weight[input_ids[r], :] with the token just chosen (rows with
  * context_lens 0 keep their token), and, if hidden_packed is not NULL, the same rows in fragment order for a following
- * nvh_linear_small_m_ex with x_packed.  embed_weight [vocab, hidden] bf16 contiguous, hidden % 32 == 0, 16-byte aligned buffers. */
+ * nvh_linear_small_m_ex with x_packed.  embed_weight [vocab, hidden] bf16 contiguous, hidden % 32 == 0, 16-byte aligned buffers.
+ * The chosen token is always a valid row of embed_weight: arg-max follows torch.argmax (NaN counts as the maximum, ties -> lowest
+ * index, an all -inf row -> 0) and the index is clamped to [0, vocab). */
 int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
                                         int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
                                         const int32_t* block_tables, int64_t bt_row_stride, int block_size,
                                         int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
-                                        const void* embed_weight, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
+                                        const void* embed_weight, int vocab, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
                                         int dtype, void* stream);
 /* offset (in elements) of activation element (row, col) of an [m, cols] matrix in fragment order */
 int64_t nvh_pack_index(int row, int col, int cols);

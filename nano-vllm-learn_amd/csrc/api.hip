@@ -104,8 +104,14 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
                              const int32_t* block_tables, const int32_t* context_lens,
                              int batch, int h, int kvh, int hd, int block_size, int max_blocks,
                              int64_t q_row_stride, int64_t bt_row_stride, float scale,
-                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream,
+                             int variant = NVH_DECODE_CHUNKED, int waves = 0, int chunks = 0) {
     if (batch == 0) return 0;
+    if (variant < NVH_DECODE_CHUNKED || variant > NVH_DECODE_SPLIT_VALU || (waves != 0 && waves != 4 && waves != 8) || chunks < 0) {
+        set_error("paged_decode: variant %d / waves %d / chunks %d not supported", variant, waves, chunks);
+        return NVH_E_SHAPE;
+    }
+    if (variant == NVH_DECODE_SPLIT_VALU && h / (kvh > 0 ? kvh : 1) > 8) { set_error("paged_decode: the VALU variant serves groups of at most 8 query heads"); return NVH_E_SHAPE; }
     if (out_packed && (!aligned16(out_packed) || ((int64_t)h * hd) % 32)) { set_error("paged_decode: out_packed needs 16-byte alignment and h*hd %% 32 == 0"); return NVH_E_ALIGN; }
     if (dtype != NVH_BF16 || (out_dtype != NVH_BF16 && out_dtype != NVH_F32)) {
         set_error("paged_decode: dtype %d / out_dtype %d unsupported", dtype, out_dtype);
@@ -146,14 +152,15 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
     a.block_size = block_size; a.max_blocks = max_blocks;
     a.num_splits = decode_num_splits(hd, max_blocks, block_size);
     // (tickets are only drawn when a (sequence, kv head) pair is split over several workgroups, i.e. when batch * kvh is small)
-    if (decode_chunks(batch, kvh, a.num_splits) > 1 && (size_t)batch * kvh * 4 > kDecodeTicketBytes) {
+    a.chunks = decode_chunks(batch, kvh, a.num_splits, chunks);
+    if (a.chunks > 1 && (size_t)batch * kvh * 4 > kDecodeTicketBytes) {
         set_error("paged_decode: batch * kvh = %d > %zu tickets", batch * kvh, kDecodeTicketBytes / 4);
         return NVH_E_SHAPE;
     }
     a.counters = reinterpret_cast<unsigned*>(workspace);
     a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeTicketBytes);
     a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;
-    a.chunks = decode_chunks(batch, kvh, a.num_splits);
+    a.impl = variant; a.waves = waves;
     a.out_packed = (uint16_t*)out_packed;
     a.q_row_stride = q_row_stride; a.bt_row_stride = bt_row_stride;
     a.scale_log2 = scale * kLog2e;
@@ -169,6 +176,15 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
                      int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
     return paged_decode_impl(out, nullptr, q, k_cache, v_cache, block_tables, context_lens, batch, h, kvh, hd, block_size, max_blocks,
                              q_row_stride, bt_row_stride, scale, dtype, out_dtype, workspace, workspace_bytes, stream);
+}
+
+int nvh_paged_decode_variant(int variant, int waves, int chunks, void* out, const void* q, const void* k_cache, const void* v_cache,
+                             const int32_t* block_tables, const int32_t* context_lens,
+                             int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                             int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return paged_decode_impl(out, nullptr, q, k_cache, v_cache, block_tables, context_lens, batch, h, kvh, hd, block_size, max_blocks,
+                             q_row_stride, bt_row_stride, scale, dtype, out_dtype, workspace, workspace_bytes, stream, variant, waves, chunks);
 }
 
 int nvh_paged_decode_packed(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
@@ -196,13 +212,17 @@ int nvh_decode_step(void* out, const void* q, const void* k_new, const void* v_n
                             workspace, workspace_bytes, stream);
 }
 
-int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
+static int prefill_varlen_impl(int kernel, int short_waves, void* out, const void* q, const void* k, const void* v,
                        const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                        const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
                        int h, int kvh, int hd, int block_size, int max_blocks,
                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                        int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream) {
     if (batch == 0 || max_seqlen_q == 0) return 0;
+    if (kernel < 0 || kernel > 2 || (short_waves != 0 && short_waves != 8 && short_waves != 16)) {
+        set_error("prefill_varlen: kernel %d / short_waves %d not supported", kernel, short_waves);
+        return NVH_E_SHAPE;
+    }
     if (dtype != NVH_BF16 || (out_dtype != NVH_BF16 && out_dtype != NVH_F32)) {
         set_error("prefill_varlen: dtype %d / out_dtype %d unsupported", dtype, out_dtype);
         return NVH_E_DTYPE;
@@ -239,7 +259,28 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
     a.scale_log2 = scale * kLog2e;
     a.out_f32 = out_dtype == NVH_F32;
     a.stamps = g_stamps;
+    a.kernel = kernel; a.short_waves = short_waves;
     return launch_prefill_varlen(a, (hipStream_t)stream);
+}
+
+int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
+                       const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                       const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
+                       int h, int kvh, int hd, int block_size, int max_blocks,
+                       int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                       int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream) {
+    return prefill_varlen_impl(0, 0, out, q, k, v, cu_seqlens_q, cu_seqlens_k, block_tables, batch, max_seqlen_q, max_seqlen_k, h, kvh, hd,
+                               block_size, max_blocks, q_row_stride, k_row_stride, v_row_stride, bt_row_stride, scale, dtype, out_dtype, stream);
+}
+
+int nvh_prefill_varlen_variant(int kernel, int short_waves, void* out, const void* q, const void* k, const void* v,
+                               const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                               const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
+                               int h, int kvh, int hd, int block_size, int max_blocks,
+                               int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                               int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream) {
+    return prefill_varlen_impl(kernel, short_waves, out, q, k, v, cu_seqlens_q, cu_seqlens_k, block_tables, batch, max_seqlen_q, max_seqlen_k, h, kvh, hd,
+                               block_size, max_blocks, q_row_stride, k_row_stride, v_row_stride, bt_row_stride, scale, dtype, out_dtype, stream);
 }
 
 int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,
@@ -416,7 +457,7 @@ static int greedy_advance_candidates_impl(const float* candidate_val, const int3
                                   int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
                                   const int32_t* block_tables, int64_t bt_row_stride, int block_size,
                                   int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
-                                  const void* embed, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed, void* stream) {
+                                  const void* embed, int vocab, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed, void* stream) {
     if (n_rows == 0) return 0;
     if (!candidate_val || !candidate_idx || !input_ids || !positions || !context_lens || !slot_mapping || !block_tables || !tokens_log || !row_steps) {
         set_error("greedy_advance_candidates: null pointer");
@@ -426,6 +467,7 @@ static int greedy_advance_candidates_impl(const float* candidate_val, const int3
     AdvanceArgs adv{input_ids, positions, context_lens, slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps};
     if (embed) {
         if (!hidden_out) { set_error("greedy_advance_candidates_embed: null pointer"); return NVH_E_NULL; }
+        if (vocab <= 0) { set_error("greedy_advance_candidates_embed: vocab %d", vocab); return NVH_E_SHAPE; }
         if (hidden <= 0 || hidden % 32 != 0 || hidden_row_stride < hidden || hidden_row_stride % 8 != 0) {
             set_error("greedy_advance_candidates_embed: hidden=%d must be a multiple of 32, row stride %lld a multiple of 8 and >= hidden", hidden, (long long)hidden_row_stride);
             return NVH_E_SHAPE;
@@ -437,7 +479,7 @@ static int greedy_advance_candidates_impl(const float* candidate_val, const int3
         adv.embed = (const uint16_t*)embed; adv.hidden = hidden; adv.hidden_out = (uint16_t*)hidden_out;
         adv.hidden_stride = hidden_row_stride; adv.hidden_packed = (uint16_t*)hidden_packed;
     }
-    return launch_argmax_candidates(candidate_val, candidate_idx, groups, candidate_stride, n_rows, adv, (hipStream_t)stream);
+    return launch_argmax_candidates(candidate_val, candidate_idx, groups, candidate_stride, n_rows, embed ? vocab : 0x7fffffff, adv, (hipStream_t)stream);
 }
 int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
                                   int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
@@ -445,20 +487,20 @@ int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* can
                                   int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps, void* stream) {
     return greedy_advance_candidates_impl(candidate_val, candidate_idx, groups, candidate_stride, n_rows, input_ids, positions, context_lens,
                                           slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps,
-                                          nullptr, 0, nullptr, 0, nullptr, stream);
+                                          nullptr, 0, 0, nullptr, 0, nullptr, stream);
 }
 int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
                                         int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,
                                         const int32_t* block_tables, int64_t bt_row_stride, int block_size,
                                         int64_t* tokens_log, int64_t log_row_stride, int64_t* row_steps,
-                                        const void* embed_weight, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
+                                        const void* embed_weight, int vocab, int hidden, void* hidden_out, int64_t hidden_row_stride, void* hidden_packed,
                                         int dtype, void* stream) {
     if (n_rows == 0) return 0;
     if (dtype != NVH_BF16) { set_error("greedy_advance_candidates_embed: dtype %d not supported (bf16 only)", dtype); return NVH_E_DTYPE; }
     if (!embed_weight) { set_error("greedy_advance_candidates_embed: null pointer"); return NVH_E_NULL; }
     return greedy_advance_candidates_impl(candidate_val, candidate_idx, groups, candidate_stride, n_rows, input_ids, positions, context_lens,
                                           slot_mapping, block_tables, bt_row_stride, block_size, tokens_log, log_row_stride, row_steps,
-                                          embed_weight, hidden, hidden_out, hidden_row_stride, hidden_packed, stream);
+                                          embed_weight, vocab, hidden, hidden_out, hidden_row_stride, hidden_packed, stream);
 }
 int64_t nvh_pack_index(int row, int col, int cols) { return pack_index(row, col, cols); }
 

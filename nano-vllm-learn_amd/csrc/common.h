@@ -100,6 +100,16 @@ __device__ __forceinline__ float slot_max(float x) {
     return x;
 }
 
+// arg-max ordering shared by every greedy kernel: torch.argmax's — NaN counts as the maximum, ties (and several NaNs) go to the
+// lowest index.  A candidate (-inf, INT_MAX) is the identity: any real element beats it, so the sentinel never survives a row
+// that holds at least one element, even an all -inf or all-NaN row.
+__device__ __forceinline__ bool argmax_better(float v, int i, float best, int bidx) {
+    const bool vn = v != v, bn = best != best;
+    if (vn != bn) return vn;
+    if (!vn && v != best) return v > best;
+    return i < bidx;
+}
+
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // v_exp_f32
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 

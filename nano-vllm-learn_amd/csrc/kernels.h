@@ -28,12 +28,14 @@ struct DecodeArgs {
     unsigned* counters;          // [B*KVH], zero before the launch, left zero by it
     int chunks;                  // workgroups per (sequence, kv head); passes are dealt to them round-robin
     uint16_t* out_packed;        // nullable: bf16 output also in MFMA-fragment order [ceil(B/16)][H*D/32][64][8] (pack_index)
+    int impl;                    // 0 chunked MFMA (default), 1 split MFMA + combine, 2 split VALU + combine (nvh_paged_decode_variant)
+    int waves;                   // chunked kernel, D = 64: 0 / 8 = eight waves per workgroup, 4 = four
 };
 
 // tokens one workgroup of the split kernel covers (static function of head_dim)
 int decode_split_tokens(int hd);
 int launch_paged_decode(const DecodeArgs& a, hipStream_t stream);
-int decode_chunks(int batch, int kvh, int num_splits);
+int decode_chunks(int batch, int kvh, int num_splits, int forced);
 
 struct RopeStoreArgs {
     uint16_t* qkv;               // [N, (H+2KVH)*D] fused projection output, rotated in place
@@ -76,8 +78,8 @@ struct AdvanceArgs {             // all null: plain argmax
     uint16_t* hidden_packed;     // nullable
 };
 int launch_argmax_rows(int64_t* out, const void* x, int n_rows, int n, int64_t stride, const AdvanceArgs& adv, hipStream_t stream);
-int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows,
-                             const AdvanceArgs& adv, hipStream_t stream);
+int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows, int vocab,
+                             const AdvanceArgs& adv, hipStream_t stream);   // vocab: chosen indices are clamped to [0, vocab)
 int linear_stream_candidate_groups(int n, int k);   // workgroups (= candidate records per row) of a NONE launch, 0 if unsupported
 
 enum { EPI_NONE = 0, EPI_SILU = 1, EPI_RESADD = 2, EPI_ROPE = 3 };   // == NVH_EPI_* in nvh_attn.h
@@ -137,6 +139,8 @@ struct PrefillArgs {
     float scale_log2;
     int out_f32;
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
+    int kernel;                  // 0 auto, 1 tiled kernel only, 2 short-sequence kernel (error if the shape does not allow it)
+    int short_waves;             // short-sequence kernel: 0 auto, 8 or 16 waves per workgroup
 };
 int launch_prefill_varlen(const PrefillArgs& a, hipStream_t stream);
 

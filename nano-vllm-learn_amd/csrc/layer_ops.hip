@@ -144,7 +144,7 @@ __device__ __forceinline__ void advance_row(const AdvanceArgs& adv, int row, int
 // Final step of the fused lm_head + argmax: per row, the best of `groups` candidates (value desc, column asc), then the
 // advance bookkeeping.  One 256-thread workgroup per row.
 __global__ __launch_bounds__(256) void argmax_candidates_kernel(const float* __restrict__ cand_val, const int32_t* __restrict__ cand_idx,
-                                                                 int groups, int64_t cand_stride, const AdvanceArgs adv) {
+                                                                 int groups, int64_t cand_stride, int vocab, const AdvanceArgs adv) {
     __shared__ float lds_v[4];
     __shared__ int lds_i[4];
     const int row = blockIdx.x;
@@ -153,19 +153,22 @@ __global__ __launch_bounds__(256) void argmax_candidates_kernel(const float* __r
     for (int gi = threadIdx.x; gi < groups; gi += 256) {
         const float v = cand_val[(int64_t)gi * cand_stride + row];
         const int i = cand_idx[(int64_t)gi * cand_stride + row];
-        if (v > best || (v == best && i < bidx)) { best = v; bidx = i; }
+        if (argmax_better(v, i, best, bidx)) { best = v; bidx = i; }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(bidx, off, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        if (argmax_better(ov, oi, best, bidx)) { best = ov; bidx = oi; }
     }
     if ((threadIdx.x & 63) == 0) { lds_v[threadIdx.x >> 6] = best; lds_i[threadIdx.x >> 6] = bidx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 4; ++w)
-            if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+            if (argmax_better(lds_v[w], lds_i[w], best, bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+        // a valid token whatever the candidates held (the index feeds an embedding-row address below): the ordering above never
+        // lets the (-inf, INT_MAX) identity survive a real candidate; the clamp covers corrupt candidate indices as well
+        bidx = bidx < 0 ? 0 : (bidx >= vocab ? vocab - 1 : bidx);
         if (adv.embed) lds_i[0] = adv.context_lens[row] > 0 ? bidx : (int)adv.input_ids[row];   // padding rows keep their token
         advance_row(adv, row, bidx);
     }
@@ -195,27 +198,28 @@ __global__ __launch_bounds__(1024) void argmax_rows_kernel(int64_t* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float lo = bf16_lo(v[k]), hi = bf16_hi(v[k]);
-            if (lo > best) { best = lo; bidx = c * 8 + 2 * k; }            // ascending index order inside a thread: first max wins
-            if (hi > best) { best = hi; bidx = c * 8 + 2 * k + 1; }
+            if (argmax_better(lo, c * 8 + 2 * k, best, bidx)) { best = lo; bidx = c * 8 + 2 * k; }
+            if (argmax_better(hi, c * 8 + 2 * k + 1, best, bidx)) { best = hi; bidx = c * 8 + 2 * k + 1; }
         }
     }
     for (int i = chunks * 8 + threadIdx.x; i < n; i += 1024) {              // tail when n % 8 != 0
         const float f = bf16_lo((uint32_t)row[i]);
-        if (f > best) { best = f; bidx = i; }
+        if (argmax_better(f, i, best, bidx)) { best = f; bidx = i; }
     }
-    // wave reduce (value desc, index asc), then across the 16 waves
+    // wave reduce (torch.argmax order: NaN first, value desc, index asc), then across the 16 waves
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         const float ov = __shfl_xor(best, off, 64);
         const int oi = __shfl_xor(bidx, off, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        if (argmax_better(ov, oi, best, bidx)) { best = ov; bidx = oi; }
     }
     const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { lds_v[wave] = best; lds_i[wave] = bidx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < 16; ++w)
-            if (lds_v[w] > best || (lds_v[w] == best && lds_i[w] < bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+            if (argmax_better(lds_v[w], lds_i[w], best, bidx)) { best = lds_v[w]; bidx = lds_i[w]; }
+        bidx = bidx < 0 ? 0 : (bidx >= n ? n - 1 : bidx);             // n >= 1 (host): always a valid column
         if (out) out[blockIdx.x] = bidx;
         if (adv.input_ids) advance_row(adv, blockIdx.x, bidx);
     }
@@ -240,10 +244,10 @@ int launch_residual_add_pack(void* residual, const void* y, void* packed, int n_
     return check_launch("residual_add_pack");
 }
 
-int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows,
+int launch_argmax_candidates(const float* cand_val, const int32_t* cand_idx, int groups, int64_t cand_stride, int n_rows, int vocab,
                              const AdvanceArgs& adv, hipStream_t stream) {
     if (n_rows == 0) return 0;
-    hipLaunchKernelGGL(argmax_candidates_kernel, dim3(n_rows), dim3(256), 0, stream, cand_val, cand_idx, groups, cand_stride, adv);
+    hipLaunchKernelGGL(argmax_candidates_kernel, dim3(n_rows), dim3(256), 0, stream, cand_val, cand_idx, groups, cand_stride, vocab, adv);
     return check_launch("argmax_candidates");
 }
 

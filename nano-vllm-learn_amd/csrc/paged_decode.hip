@@ -961,8 +961,8 @@ int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
 template <int D>
 int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
     // D = 64: 8 waves (two per SIMD, 32-token tiles) measured 8.5 % faster than 4 waves of 64-token tiles (ctx 1536: 11.0 ->
-    // 10.05 us per call); NVH_DECODE_WAVES=4 selects the old shape for A/B.  D = 128 keeps 4 waves (its images are twice as large).
-    static const int waves = [] { const char* e = getenv("NVH_DECODE_WAVES"); return e ? atoi(e) : 8; }();
+    // 10.05 us per call); a.waves = 4 (nvh_paged_decode_variant) selects the old shape.  D = 128 keeps 4 waves (its images are twice as large).
+    const int waves = a.waves == 4 ? 4 : 8;
     dim3 grid(a.kvh, a.batch, a.chunks);
     const int bs_shift = (a.block_size & (a.block_size - 1)) == 0 ? __builtin_ctz(a.block_size) : -1;
     if constexpr (D == 64) {
@@ -992,20 +992,21 @@ static_assert(MGeo<64>::SPLIT == Geo<64>::SPLIT && MGeo<128>::SPLIT == Geo<128>:
 
 int decode_max_group(void) { return 16; }
 
-// NVH_DECODE_IMPL selects an older formulation for A/B measurements: "valu" = VALU split kernel (groups <= 8) + combine,
-// "split" = single-pass MFMA split kernel + combine; default = the chunked MFMA kernel (one launch).
-static int decode_impl() {
-    static const int v = [] {
-        const char* e = getenv("NVH_DECODE_IMPL");
-        return !e ? 0 : e[0] == 'v' ? 1 : e[0] == 's' ? 2 : 0;
+// compute units of the current device (256 on MI355X), read once: a device property, not a tuning knob
+static int device_cus() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
     }();
-    return v;
+    return n;
 }
 
-// workgroups per (sequence, kv head): one wave of workgroups over the chip, at most one per pass
-int decode_chunks(int batch, int kvh, int num_splits) {
-    static const int forced = [] { const char* e = getenv("NVH_DECODE_CHUNKS"); return e ? atoi(e) : 0; }();   // A/B knob
-    int c = forced > 0 ? forced : (256 + batch * kvh / 2) / (batch * kvh);
+// workgroups per (sequence, kv head): one wave of workgroups over the chip, at most one per pass; `forced` > 0 (the
+// variant entry point, tests and A/B runs) overrides the choice
+int decode_chunks(int batch, int kvh, int num_splits, int forced) {
+    const int cus = device_cus();
+    int c = forced > 0 ? forced : (cus + batch * kvh / 2) / (batch * kvh);
     if (c < 1) c = 1;
     return c > num_splits ? num_splits : c;
 }
@@ -1013,10 +1014,12 @@ int decode_chunks(int batch, int kvh, int num_splits) {
 int launch_paged_decode(const DecodeArgs& a, hipStream_t stream) {
     if (a.batch == 0) return 0;
     const int g = a.h / a.kvh;
-    const int impl = decode_impl();
-    if (impl != 0 && a.out_packed) { set_error("paged_decode: out_packed needs the chunked kernel (unset NVH_DECODE_IMPL)"); return -2; }
-    if (impl == 1 && g <= 8) return a.hd == 64 ? launch_valu_d<64>(a, g, stream) : launch_valu_d<128>(a, g, stream);
-    if (impl == 2) return a.hd == 64 ? launch_mfma<64>(a, g, stream) : launch_mfma<128>(a, g, stream);
+    // a.impl (nvh_paged_decode_variant): 0 = the chunked MFMA kernel (one launch; what nvh_paged_decode runs), 1 = single-pass MFMA
+    // split kernel + combine, 2 = VALU split kernel (groups <= 8) + combine — the older formulations, kept for A/B and parity-tested
+    const int impl = a.impl;
+    if (impl != 0 && a.out_packed) { set_error("paged_decode: out_packed needs the chunked kernel"); return -2; }
+    if (impl == 2) return a.hd == 64 ? launch_valu_d<64>(a, g, stream) : launch_valu_d<128>(a, g, stream);
+    if (impl == 1) return a.hd == 64 ? launch_mfma<64>(a, g, stream) : launch_mfma<128>(a, g, stream);
     return a.hd == 64 ? launch_chunked<64>(a, g, stream) : launch_chunked<128>(a, g, stream);
 }
 

@@ -424,7 +424,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, lg = lane >> 4;
-    const int n_tiles = (sk + BN - 1) / BN;          // <= NKT (host)
+    int n_tiles = (sk + BN - 1) / BN;                // <= NKT by the caller's contract (max_seqlen_k bounds every sequence);
+    if (n_tiles > NKT) n_tiles = NKT;                // a caller that understated it must not make the staging loop write past the array
 
     // ---- stage every K / V tile of the sequence: DMA instruction `ins` = 1 KiB of one image, dealt round-robin to the waves
     {
@@ -628,12 +629,11 @@ int launch_q(const PrefillArgs& a, hipStream_t stream) {
     return check_launch("prefill_varlen");
 }
 
-// NVH_PREFILL_SHORT: 0 = never, 2 = whenever the shape allows (tests), default = when it also fills the chip
+// a.kernel (nvh_prefill_varlen_variant): 1 = never, 2 = whenever the shape allows (tests), 0 = when it also fills the chip
 template <int D>
 int launch_short(const PrefillArgs& a, hipStream_t stream, bool& taken) {
     taken = false;
-    const char* e = getenv("NVH_PREFILL_SHORT");
-    const int mode = e ? atoi(e) : 1;
+    const int mode = a.kernel == 1 ? 0 : a.kernel == 2 ? 2 : 1;
     const int max_keys = 128;                                    // (256 keys with four resident tiles measured slower than the tiled kernel)
     if (mode == 0 || a.block_tables || a.max_seqlen_k > max_keys || a.max_seqlen_q > a.max_seqlen_k) return 0;
     if (mode != 2 && a.batch * a.kvh < 128) return 0;            // few sequences: the tiled kernel spreads heads and q-tiles over the CUs
@@ -642,8 +642,7 @@ int launch_short(const PrefillArgs& a, hipStream_t stream, bool& taken) {
     // a wave's tile is a long dependent chain (QK -> max -> exp2 -> hi/lo -> PV): four waves per SIMD to fill it where the registers allow
     // (measured, Qwen2-0.5B heads, S = 128: 256 workgroups 22.7 us with 16 waves against 25.2 with 8; 512 workgroups, two per CU,
     // 37.4 us with 8 against 41.9 with 16; the tiled kernel 28.3 / 56)
-    const char* w = getenv("NVH_PREFILL_SHORT_WAVES");           // A/B knob
-    const int waves = w ? atoi(w) : (a.batch * a.kvh >= 384 ? 8 : 16);
+    const int waves = a.short_waves ? a.short_waves : (a.batch * a.kvh >= 384 ? 8 : 16);
     if constexpr (D == 64) {
         if (waves == 16) {
             hipLaunchKernelGGL((prefill_short_kernel<D, 2, 16>), grid, dim3(1024), 0, stream, a);
@@ -659,6 +658,7 @@ int launch_d(const PrefillArgs& a, hipStream_t stream) {
     bool taken;
     const int rc = launch_short<D>(a, stream, taken);
     if (taken) return rc;
+    if (a.kernel == 2) { set_error("prefill_varlen: the short-sequence kernel needs max_seqlen_q <= max_seqlen_k <= 128 and no block table"); return -2; }
     const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= 2048;
     return two ? launch_q<D, 2>(a, stream) : launch_q<D, 1>(a, stream);
 }

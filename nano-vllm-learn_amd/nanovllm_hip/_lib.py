@@ -28,6 +28,8 @@ class LinearDesc(ctypes.Structure):
 
 
 EPI_NONE, EPI_SILU_MUL, EPI_RESIDUAL_ADD, EPI_ROPE_STORE = 0, 1, 2, 3
+PREFILL_KERNELS = {"auto": 0, "tiled": 1, "short": 2}                         # NVH_PREFILL_* (nvh_prefill_varlen_variant)
+DECODE_VARIANTS = {"chunked": 0, "split_mfma": 1, "split_valu": 2}      # NVH_DECODE_* (nvh_paged_decode_variant)
 
 _c_i32p = ctypes.c_void_p
 _SIGS = {
@@ -39,6 +41,9 @@ _SIGS = {
     "nvh_paged_decode": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_i32p, _c_i32p] + [ctypes.c_int] * 6 +
                          [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                           ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "nvh_paged_decode_variant": (ctypes.c_int, [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4 + [_c_i32p, _c_i32p] + [ctypes.c_int] * 6 +
+                                 [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nvh_paged_decode_packed": (ctypes.c_int, [ctypes.c_void_p] * 5 + [_c_i32p, _c_i32p] + [ctypes.c_int] * 6 +
                                 [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int,
                                  ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
@@ -47,6 +52,8 @@ _SIGS = {
                                                 ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nvh_prefill_varlen": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_i32p] * 3 + [ctypes.c_int] * 8 +
                            [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "nvh_prefill_varlen_variant": (ctypes.c_int, [ctypes.c_int] * 2 + [ctypes.c_void_p] * 4 + [_c_i32p] * 3 + [ctypes.c_int] * 8 +
+                                   [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "nvh_rope_store": (ctypes.c_int, [ctypes.c_void_p] * 5 + [ctypes.c_float] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 4 +
                        [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]),
     "nvh_add_rmsnorm": (ctypes.c_int, [ctypes.c_void_p] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int] + [ctypes.c_int64] * 3 +
@@ -67,7 +74,7 @@ _SIGS = {
     "nvh_greedy_advance_candidates_embed": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int] +
                                             [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                                                       ctypes.c_void_p] +
-                                            [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
+                                            [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int,
                                              ctypes.c_void_p]),
 }
 EXPORTS = tuple(_SIGS)

@@ -41,7 +41,15 @@ def build_block_tables(seqs, width=None, pad=-1):
     return torch.tensor(rows, dtype=torch.int32)
 
 
+def _check_block_size(seqs, block_size):
+    """Sequence.block_size is a class constant in the reference (engine/sequence.py:15) and feeds num_blocks /
+    last_block_num_tokens; a runner with another kvcache_block_size would compute slots from the wrong block."""
+    for s in seqs:
+        assert s.block_size == block_size, f"Sequence.block_size {s.block_size} != runner block size {block_size}"
+
+
 def build_prefill_meta(seqs, block_size=256):
+    _check_block_size(seqs, block_size)
     input_ids, positions, slot_mapping = [], [], []
     cu_q, cu_k = [0], [0]
     max_q = max_k = 0
@@ -67,6 +75,7 @@ def build_prefill_meta(seqs, block_size=256):
 
 
 def build_decode_meta(seqs, block_size=256):
+    _check_block_size(seqs, block_size)
     input_ids = [s.last_token for s in seqs]
     positions = [len(s) for s in seqs]
     context_lens = [len(s) for s in seqs]
@@ -81,6 +90,9 @@ class ModelRunner:
     def __init__(self, cfg: ModelConfig, num_kvcache_blocks: int, device=None, max_model_len=4096, seed=0):
         self.cfg = cfg
         self.block_size = cfg.kvcache_block_size
+        assert self.block_size == Sequence.block_size, (
+            f"kvcache_block_size {self.block_size} != Sequence.block_size {Sequence.block_size} (fixed at 256 as in the reference, "
+            "engine/sequence.py:15, config.py:20,31)")
         self.max_model_len = max_model_len
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1

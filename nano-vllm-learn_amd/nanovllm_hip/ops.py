@@ -121,18 +121,23 @@ def _decode_common(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scal
 
 
 def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale=None, causal=True,
-                            out=None, out_dtype=None, out_packed=None):
+                            out=None, out_dtype=None, out_packed=None, variant=None, waves=0, chunks=0):
     """Decode attention, drop-in for the call at attention.py:99-101.
 
     q [B, 1, H, D] (or [B, H, D]); caches [NB, bs, KVH, D]; cache_seqlens int32 [B] (0 -> zero row);
     block_table int32 [B, max_blocks].  `causal` is accepted for signature parity; with one query per
     sequence it has no effect.  Returns [B, 1, H, D] (or [B, H, D]).  out_packed: optional flat bf16 buffer of
-    ceil(B/16)*16*H*D elements that also receives the result in MFMA-fragment order (pack_rows layout) for fused_linear."""
+    ceil(B/16)*16*H*D elements that also receives the result in MFMA-fragment order (pack_rows layout) for fused_linear.
+    variant ("chunked" | "split_mfma" | "split_valu"), waves, chunks: tests / A-B only (nvh_paged_decode_variant); the module
+    path never passes them."""
     squeeze, q3, b, h, hd, kvh, bs, max_blocks, scale, out, ws = _decode_common(
         q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype)
     tail = (q3.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_table.data_ptr(), cache_seqlens.data_ptr(), b, h, kvh, hd, bs,
             max_blocks, q3.stride(0), block_table.stride(0), scale, NVH_BF16, _out_code(out.dtype), ws.data_ptr(), ws.numel(), _stream())
-    if out_packed is not None:
+    if variant is not None or waves or chunks:
+        assert out_packed is None
+        rc = _lib.load().nvh_paged_decode_variant(_lib.DECODE_VARIANTS[variant or "chunked"], int(waves), int(chunks), out.data_ptr(), *tail)
+    elif out_packed is not None:
         _require_gpu_bf16(out_packed=out_packed)
         assert out_packed.is_contiguous() and out_packed.numel() >= ((b + 15) // 16) * 16 * h * hd
         rc = _lib.load().nvh_paged_decode_packed(out.data_ptr(), out_packed.data_ptr(), *tail)
@@ -164,11 +169,12 @@ def decode_step(q, k_new, v_new, k_cache, v_cache, slot_mapping, cache_seqlens, 
 
 # --------------------------------------------------------------------------------------- prefill
 def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu_seqlens_k, softmax_scale=None,
-                           causal=True, block_table=None, out_dtype=None):
+                           causal=True, block_table=None, out_dtype=None, kernel=None, short_waves=0):
     """Packed varlen causal attention, drop-in for the call at attention.py:93-96.
 
     q [Tq, H, D]; without block_table k/v are [Tk, KVH, D] (any row stride); with block_table they are
-    the paged caches [NB, bs, KVH, D] and sequence i reads its keys through block_table[i]."""
+    the paged caches [NB, bs, KVH, D] and sequence i reads its keys through block_table[i].
+    kernel ("auto" | "tiled" | "short"), short_waves: tests / A-B only (nvh_prefill_varlen_variant)."""
     if not causal:
         raise NotImplementedError("the reference only ever calls this with causal=True (attention.py:96)")
     tq, h, hd = q.shape
@@ -193,11 +199,13 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
         assert k.stride(-1) == 1 and v.stride(-1) == 1 and k.stride(1) == hd and v.stride(1) == hd
         bs, max_blocks, bt_stride, bt_ptr = 0, 0, 0, None
         k_stride, v_stride = k.stride(0), v.stride(0)
-    rc = _lib.load().nvh_prefill_varlen(out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(),
-                                        cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), bt_ptr, batch,
-                                        int(max_seqlen_q), int(max_seqlen_k), h, kvh, hd, bs, max_blocks,
-                                        q.stride(0), k_stride, v_stride, bt_stride, float(softmax_scale),
-                                        NVH_BF16, _out_code(out.dtype), _stream())
+    tail = (out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), bt_ptr, batch,
+            int(max_seqlen_q), int(max_seqlen_k), h, kvh, hd, bs, max_blocks, q.stride(0), k_stride, v_stride, bt_stride,
+            float(softmax_scale), NVH_BF16, _out_code(out.dtype), _stream())
+    if kernel is not None or short_waves:
+        rc = _lib.load().nvh_prefill_varlen_variant(_lib.PREFILL_KERNELS[kernel or "auto"], int(short_waves), *tail)
+    else:
+        rc = _lib.load().nvh_prefill_varlen(*tail)
     _lib.check(rc, "nvh_prefill_varlen")
     return out
 
@@ -415,7 +423,7 @@ def greedy_advance_candidates(cand_val, cand_idx, groups, n_rows, input_ids, pos
         rc = _lib.load().nvh_greedy_advance_candidates_embed(
             cand_val.data_ptr(), cand_idx.data_ptr(), groups, cand_val.stride(0), n_rows, input_ids.data_ptr(), positions.data_ptr(),
             context_lens.data_ptr(), slot_mapping.data_ptr(), block_tables.data_ptr(), block_tables.stride(0), block_size,
-            tokens_log.data_ptr(), tokens_log.stride(0), row_steps.data_ptr(), w.data_ptr(), w.shape[1], hid.data_ptr(), hid.stride(0),
+            tokens_log.data_ptr(), tokens_log.stride(0), row_steps.data_ptr(), w.data_ptr(), w.shape[0], w.shape[1], hid.data_ptr(), hid.stride(0),
             None if packed is None else packed.data_ptr(), NVH_BF16, _stream())
         _lib.check(rc, "nvh_greedy_advance_candidates_embed")
         return

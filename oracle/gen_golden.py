@@ -145,14 +145,14 @@ def gen_meta(name):
     out = {}
     with mock.patch.object(torch, "tensor", cpu_tensor), mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self):
         sh = Shell()
-        _, pos = mr.ModelRunner.prepare_decode(sh, dec_seqs)
+        ids, pos = mr.ModelRunner.prepare_decode(sh, dec_seqs)
         c = get_context()
-        out.update(dec_tokens=[len(s) for s in dec_seqs], dec_positions=pos.numpy(), dec_slot_mapping=c.slot_mapping.numpy(),
+        out.update(dec_input_ids=ids.numpy(), dec_tokens=[len(s) for s in dec_seqs], dec_positions=pos.numpy(), dec_slot_mapping=c.slot_mapping.numpy(),
                    dec_context_lens=c.context_lens.numpy(), dec_block_tables=c.block_tables.numpy())
         for tag, seqs in (("pre", pre_seqs), ("pfx", pfx_seqs)):
-            _, pos = mr.ModelRunner.prepare_prefill(sh, seqs)
+            ids, pos = mr.ModelRunner.prepare_prefill(sh, seqs)
             c = get_context()
-            out.update({f"{tag}_tokens": [len(s) for s in seqs], f"{tag}_cached": [s.num_cached_tokens for s in seqs],
+            out.update({f"{tag}_input_ids": ids.numpy(), f"{tag}_tokens": [len(s) for s in seqs], f"{tag}_cached": [s.num_cached_tokens for s in seqs],
                         f"{tag}_positions": pos.numpy(), f"{tag}_cu_seqlens_q": c.cu_seqlens_q.numpy(),
                         f"{tag}_cu_seqlens_k": c.cu_seqlens_k.numpy(),
                         f"{tag}_max_seqlen": np.array([c.max_seqlen_q, c.max_seqlen_k]),
@@ -161,6 +161,37 @@ def gen_meta(name):
         for tag, seqs in (("dec", dec_seqs), ("pre", pre_seqs), ("pfx", pfx_seqs)):
             w = max(len(s.block_table) for s in seqs)
             out[f"{tag}_tables_in"] = np.array([s.block_table + [-9] * (w - len(s.block_table)) for s in seqs], dtype=np.int32)
+        # a decode TRAJECTORY: the reference's own between-steps bookkeeping (scheduler.py:60-110: may_append before the step,
+        # append_token after it; block_manager.py:62-159) driven for 300 steps across block boundaries, prepare_decode's
+        # tensors recorded at every step.  Token ids come from a seeded generator (the model is not part of this path).
+        from nanovllm.engine.block_manager import BlockManager
+        bm = BlockManager(64, 256)
+        gen = torch.Generator().manual_seed(77)
+        traj_lens = [255, 256, 1, 511, 700, 130]
+        traj_seqs = []
+        for n in traj_lens:
+            s = Sequence(torch.randint(0, 10000, (n,), generator=gen).tolist())
+            bm.allocate(s)
+            traj_seqs.append(s)
+        steps = 300
+        toks = torch.randint(0, 10000, (steps + 1, len(traj_seqs)), generator=gen)
+        for s, t in zip(traj_seqs, toks[0].tolist()):            # the token prefill sampled (postprocess of the prefill step)
+            s.append_token(t)
+        rec = {k: [] for k in ("input_ids", "positions", "slot_mapping", "context_lens")}
+        for i in range(steps):
+            for s in traj_seqs:
+                assert bm.can_append(s)
+                bm.may_append(s)                                  # scheduler.schedule, decode branch
+            ids, pos = mr.ModelRunner.prepare_decode(sh, traj_seqs)
+            c = get_context()
+            rec["input_ids"].append(ids.numpy()); rec["positions"].append(pos.numpy())
+            rec["slot_mapping"].append(c.slot_mapping.numpy()); rec["context_lens"].append(c.context_lens.numpy())
+            for s, t in zip(traj_seqs, toks[i + 1].tolist()):    # scheduler.postprocess
+                s.append_token(t)
+        w = max(len(s.block_table) for s in traj_seqs)
+        out.update(traj_prompt_lens=np.array(traj_lens), traj_tokens=toks.numpy(),
+                   traj_final_tables=np.array([s.block_table + [-1] * (w - len(s.block_table)) for s in traj_seqs], dtype=np.int32),
+                   **{f"traj_{k}": np.stack(v) for k, v in rec.items()})
     np.savez_compressed(os.path.join(OUT, name), **out)
     print(name, "keys", len(out))
 
@@ -183,6 +214,9 @@ def gen_rope(name, seed, heads, D, n_tokens, base=1000000.0, max_position=4096):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if sys.argv[1:] == ["meta"]:                     # only the runner-metadata fixture (leaves the other files' bytes alone)
+        gen_meta("meta_runner.npz")
+        return
     # (1) decode: three shape sets, edge context lengths, -1 and 0 padding, a ctx==0 row
     gen_decode("decode_q2_0p5b.npz", 1, 14, 2, 64, [700, 257, 0, 256], pad=-1)
     gen_decode("decode_q2_0p5b_graphpad.npz", 2, 14, 2, 64, [255, 1, 17, 0, 300], pad=0, width=16)

@@ -75,15 +75,31 @@ def test_store_kvcache_empty_and_all_skipped(ops):
 
 
 # ------------------------------------------------------------------------------------------ decode
+# Every decode formulation shipped in the library (nvh_paged_decode_variant): the default chunked MFMA kernel with 8 and with 4
+# waves, forced chunk counts (1 = no hand-off, 3 / 16 = uneven / maximal hand-off), the single-pass MFMA split kernel + combine,
+# and north_star's literal VALU + wavefront-reduction form + combine.  {} = the plain nvh_paged_decode call.
+VARIANTS = {
+    "default": {},
+    "chunked_w4": dict(variant="chunked", waves=4),
+    "chunked_c1": dict(variant="chunked", chunks=1),
+    "chunked_c3": dict(variant="chunked", chunks=3),
+    "chunked_c16_w4": dict(variant="chunked", chunks=16, waves=4),
+    "split_mfma": dict(variant="split_mfma"),
+    "split_valu": dict(variant="split_valu"),
+}
+
+
+@pytest.mark.parametrize("vname", list(VARIANTS))
 @pytest.mark.parametrize("name", DECODE)
-def test_paged_decode_golden(ops, golden, name):
+def test_paged_decode_golden(ops, golden, name, vname):
     g = golden(name)
+    kw = VARIANTS[vname]
     q, kc, vc = dev_bf16(g["q"]), dev_bf16(g["k_cache"]), dev_bf16(g["v_cache"])
     cl, bt = dev_i32(g["context_lens"]), dev_i32(g["block_tables"])
-    o32 = ops.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, cl, bt, out_dtype=torch.float32)[:, 0]
-    o16 = ops.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, cl, bt)[:, 0]
+    o32 = ops.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, cl, bt, out_dtype=torch.float32, **kw)[:, 0]
+    o16 = ops.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, cl, bt, **kw)[:, 0]
     torch.cuda.synchronize()
-    check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), g["expected"], name)
+    check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), g["expected"], f"{name} [{vname}]")
     for b in np.where(g["context_lens"] == 0)[0]:
         assert not o32[b].any() and not o16[b].any()
 
@@ -123,10 +139,15 @@ def test_paged_decode_vs_oracle(ops, B, H, KVH, D, lo, hi, width, pad):
     exp = O.paged_decode(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), ctxs, bt)
     qd, kd, vd = q.cuda(), kc.cuda(), vc.cuda()
     cl, btd = dev_i32(ctxs), dev_i32(bt)
-    o32 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, out_dtype=torch.float32)
-    o16 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd)
-    torch.cuda.synchronize()
-    check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"decode B{B} H{H}/{KVH} D{D}")
+    for vname, kw in VARIANTS.items():                          # one oracle evaluation, every shipped formulation held to it
+        if kw.get("variant") == "split_valu" and H // KVH > 8:
+            continue                                            # the VALU form serves groups of at most 8 (refused by the ABI)
+        if kw.get("chunks", 0) > 1 and B * KVH > 16384:
+            continue
+        o32 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, out_dtype=torch.float32, **kw)
+        o16 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, **kw)
+        torch.cuda.synchronize()
+        check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"decode B{B} H{H}/{KVH} D{D} [{vname}]")
 
 
 @pytest.mark.parametrize("bs", [64, 128, 192, 320, 512])
@@ -554,6 +575,15 @@ def test_paged_decode_randomised_shapes(seed):
     torch.cuda.synchronize()
     assert torch.equal(o32, again)                               # the last-arriver merge is order-fixed: bitwise repeatable
     check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"decode seed {seed} B{B} H{H}/{KVH} D{D} hi{hi} width{width}")
+    # the other shipped formulations on the same geometry (a random chunk count included)
+    extra = dict(VARIANTS, chunked_rand=dict(variant="chunked", chunks=int(rng.integers(1, 9)), waves=int(rng.choice([4, 8]))))
+    for vname, kw in extra.items():
+        if not kw:
+            continue
+        v32 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, out_dtype=torch.float32, **kw)
+        v16 = ops.flash_attn_with_kvcache(qd, kd, vd, cl, btd, **kw)
+        torch.cuda.synchronize()
+        check_close(v32.cpu().numpy(), v16.float().cpu().numpy(), exp, f"decode seed {seed} [{vname} {kw}] B{B} H{H}/{KVH} D{D} hi{hi} width{width}")
 
 
 @pytest.mark.gpu
@@ -588,9 +618,9 @@ def test_prefill_randomised_varlen(seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", list(range(12)))
-def test_prefill_short_sequence_kernel(seed, monkeypatch):
-    """The resident-K/V kernel for short sequences (one workgroup per (sequence, kv head), NVH_PREFILL_SHORT=2 forces it on
-    any batch size) against the oracle and against the tiled kernel: lengths on the 16-row sub-tile and 64-key tile
+def test_prefill_short_sequence_kernel(seed):
+    """The resident-K/V kernel for short sequences (one workgroup per (sequence, kv head); kernel="short" of
+    nvh_prefill_varlen_variant forces it on any batch size, with 8 and with 16 waves) against the oracle and against the tiled kernel: lengths on the 16-row sub-tile and 64-key tile
     boundaries, up to 128 keys, G in 1..8, strided views, and queries that are a suffix of
     the keys (bottom-right causal alignment)."""
     from nanovllm_hip import ops
@@ -615,11 +645,12 @@ def test_prefill_short_sequence_kernel(seed, monkeypatch):
     kvd, qqd = kv.cuda(), qq.cuda()
     qd, kd, vd = qqd[:, :H * D].view(Tq, H, D), kvd[:, :KVH * D].view(Tk, KVH, D), kvd[:, KVH * D:].view(Tk, KVH, D)
     outs = {}
-    for mode in ("2", "0"):
-        monkeypatch.setenv("NVH_PREFILL_SHORT", mode)
-        o32 = ops.flash_attn_varlen_func(qd, kd, vd, max(qlens), dev_i32(cuq), max(klens), dev_i32(cuk), out_dtype=torch.float32)
-        o16 = ops.flash_attn_varlen_func(qd, kd, vd, max(qlens), dev_i32(cuq), max(klens), dev_i32(cuk))
+    for mode, waves in (("short", 8), ("short", 16), ("tiled", 0)):
+        kw = dict(kernel=mode, short_waves=waves)
+        o32 = ops.flash_attn_varlen_func(qd, kd, vd, max(qlens), dev_i32(cuq), max(klens), dev_i32(cuk), out_dtype=torch.float32, **kw)
+        o16 = ops.flash_attn_varlen_func(qd, kd, vd, max(qlens), dev_i32(cuq), max(klens), dev_i32(cuk), **kw)
         torch.cuda.synchronize()
-        check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"short prefill mode {mode} seed {seed} H{H}/{KVH} D{D} q{qlens} k{klens}")
-        outs[mode] = o32
-    assert (outs["2"] - outs["0"]).abs().max().item() <= 2e-4    # same arithmetic per (row, key tile); only the tile schedule differs
+        check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), exp, f"short prefill {mode}/{waves} seed {seed} H{H}/{KVH} D{D} q{qlens} k{klens}")
+        outs[mode, waves] = o32
+    for key in (("short", 8), ("short", 16)):                    # same arithmetic per (row, key tile); only the tile schedule differs
+        assert (outs[key] - outs["tiled", 0]).abs().max().item() <= 2e-4

@@ -21,11 +21,10 @@ for c in range(cases):
     cuq = torch.tensor(np.concatenate([[0], np.cumsum(qlens)]), dtype=torch.int32, device="cuda")
     cuk = torch.tensor(np.concatenate([[0], np.cumsum(klens)]), dtype=torch.int32, device="cuda")
     outs = []
-    for mode in ("2", "0"):
-        os.environ["NVH_PREFILL_SHORT"] = mode
-        for waves in (("8", "16") if mode == "2" and D == 64 else ("8",)):
-            os.environ["NVH_PREFILL_SHORT_WAVES"] = waves
-            outs.append(ops.flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], int(qlens.max()), cuq, int(klens.max()), cuk, out_dtype=torch.float32))
+    for mode in ("short", "tiled"):
+        for waves in ((8, 16) if mode == "short" and D == 64 else (8,)):
+            outs.append(ops.flash_attn_varlen_func(q, kv[:, 0], kv[:, 1], int(qlens.max()), cuq, int(klens.max()), cuk, out_dtype=torch.float32,
+                                                   kernel=mode, short_waves=waves if mode == "short" else 0))
     torch.cuda.synchronize()
     for o in outs[:-1]:
         assert torch.isfinite(o).all()
