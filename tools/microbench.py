@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time a HIP graph of `layers` back-to-back launches")
     ap.add_argument("--fused", action="store_true", help="decode: time nvh_decode_step (store + attend)")
     ap.add_argument("--seq", type=int, default=1024, help="prefill: sequence length")
+    ap.add_argument("--variant", default=None, help="decode: chunked | split_mfma | split_valu (nvh_paged_decode_variant); prefill: auto | tiled | short")
+    ap.add_argument("--waves", type=int, default=0, help="decode (chunked, D=64): 4 or 8 waves; prefill short kernel: 8 or 16")
+    ap.add_argument("--chunks", type=int, default=0, help="decode (chunked): workgroups per (sequence, kv head)")
     args = ap.parse_args()
     dev = "cuda"
     torch.manual_seed(0)
@@ -94,7 +97,7 @@ def main():
             if args.fused:
                 ops.decode_step(q, knew, knew, caches[l][0], caches[l][1], slots, cl, bt, out=out)
             else:
-                ops.flash_attn_with_kvcache(q, caches[l][0], caches[l][1], cl, bt, out=out)
+                ops.flash_attn_with_kvcache(q, caches[l][0], caches[l][1], cl, bt, out=out, variant=args.variant, waves=args.waves, chunks=args.chunks)
 
         if args.graph:
             for l in range(args.layers):
@@ -120,7 +123,7 @@ def main():
         k = qkv[:, h * d:(h + kvh) * d].view(t, kvh, d)
         v = qkv[:, (h + kvh) * d:].view(t, kvh, d)
         cu = torch.arange(0, t + 1, s, dtype=torch.int32, device=dev)
-        us = time_loop(lambda l: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu), 1, args.iters, args.warmup)
+        us = time_loop(lambda l: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu, kernel=args.variant, short_waves=args.waves), 1, args.iters, args.warmup)
         flops = b * 4 * d * h * s * (s + 1) / 2
         print(json.dumps({"mode": "prefill", "batch": b, "seq": s, "shape": [h, kvh, d], "us_per_call": round(us, 1),
                           "TFLOPs": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}))
