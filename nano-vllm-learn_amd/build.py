@@ -58,6 +58,49 @@ def _compile(src, asm, extra=(), obj_dir=None):
     return obj
 
 
+def audit_ticket_registers(asm_path):
+    """The decode kernel draws its arrival ticket with an inline-asm returning atomic whose result lands long after the statement
+    (csrc/paged_decode.hip, NVH_TICKET_DRAW) and claims it behind an explicit wait (NVH_TICKET_CLAIM).  hipcc does not know the
+    register is in flight: this audit proves, on the ISA that was actually emitted, that NO instruction between the two
+    markers names the destination VGPR (alone or inside a register range).  Returns the number of draw sites checked."""
+    import re
+    lines = open(asm_path).read().split("\n")
+    checked = 0
+    i = 0
+    while i < len(lines):
+        if "NVH_TICKET_DRAW" in lines[i] and "global_atomic_add" in lines[i]:
+            m = re.search(r"global_atomic_add\s+v(\d+)\s*,", lines[i])
+            if not m:
+                raise RuntimeError(f"{asm_path}:{i + 1}: cannot parse the ticket draw: {lines[i].strip()}")
+            reg = int(m.group(1))
+            j = i + 1
+            while j < len(lines) and "NVH_TICKET_CLAIM" not in lines[j]:
+                code = lines[j].split(";")[0]
+                if ".Lfunc_end" in code or code.strip().startswith(".size"):
+                    raise RuntimeError(f"{asm_path}:{i + 1}: ticket drawn but never claimed before the function ends")
+                hit = re.search(rf"\bv{reg}\b", code) is not None
+                for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code):
+                    hit = hit or int(a) <= reg <= int(b)
+                if hit and not code.strip().startswith(("s_mov_b64 exec", ";;")):
+                    raise RuntimeError(f"{asm_path}:{j + 1}: v{reg} (ticket in flight since line {i + 1}) is touched before the claim: {lines[j].strip()}")
+                j += 1
+            if j == len(lines):
+                raise RuntimeError(f"{asm_path}:{i + 1}: ticket drawn but no NVH_TICKET_CLAIM follows")
+            checked += 1
+            i = j
+        i += 1
+    if checked == 0:
+        raise RuntimeError(f"{asm_path}: no NVH_TICKET_DRAW site found (the audit is stale)")
+    return checked
+
+
+def _emit_asm(src):
+    flags = [*FLAGS, *FILE_FLAGS.get(src, [])]
+    out = os.path.join(OBJ_DIR, src.replace(".hip", ".audit.s"))
+    subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True)
+    return out
+
+
 def build(force=False, asm=False, verbose=True):
     """Compile every HIP source for gfx950 and link libnvh_attn.so.  Returns the library path."""
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -71,7 +114,11 @@ def build(force=False, asm=False, verbose=True):
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; set HIPCC")
     with ThreadPoolExecutor(max_workers=4) as ex:
+        audit = ex.submit(_emit_asm, "paged_decode.hip")          # same flags as the object: the ISA the library ships
         objs = list(ex.map(lambda s: _compile(s, asm), SOURCES))
+        n = audit_ticket_registers(audit.result())
+    if verbose:
+        print(f"[nvh build] ISA audit: {n} ticket draw sites, destination register untouched until the claim")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], check=True)
     with open(stamp, "w") as f:
         f.write(digest)

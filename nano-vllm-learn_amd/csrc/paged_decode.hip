@@ -326,6 +326,19 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
     return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// Chunk records of the chunked kernel travel as self-validating 8-byte granules {value, tag}: ONE naturally aligned 8-byte
+// write-through store per granule (relaxed agent-scope atomic store = global_store_dwordx2 sc1), read back by relaxed agent-scope
+// 8-byte loads (global_load_dwordx2 sc1, past the reader's L1).  A reader that sees the launch's tag sees the value written with
+// it; no ordering between different granules is needed, hence no store drain, no flag and no fence.
+// The tag is a NaN bit pattern no partial result carries (the split + combine variants keep plain floats in the same region).
+typedef unsigned long long u64;
+constexpr unsigned kGranuleTag = 0xFFD5A1ECu;
+__device__ __forceinline__ void st_granule(u64* p, float v, unsigned tag) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_granule(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+
 template <int D>
 __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const DecodeArgs a, const int G) {
     using geo = MGeo<D>;
@@ -513,11 +526,23 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //     latency, merge, epilogue) are paid once per 2-8 passes instead of once per pass.
 //   * each wave owns two K + V image pairs (double buffer) and runs the online softmax over its passes without any
 //     workgroup barrier: pass p+1's LDS-DMA is issued before pass p is consumed, behind counted vmcnt waits.
-//   * the waves merge through LDS once; with more than one live chunk the workgroup publishes its (max, sum, O) record
-//     write-through (sc1 stores, vmcnt(0), barrier, ticket by a relaxed agent atomic) and the LAST ARRIVER of the
-//     (sequence, kv head) merges all records (sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
-//     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
-//     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
+//   * the waves merge through LDS once.  With more than one live chunk, the hand-off to the workgroup that writes the output is
+//     (a) a TICKET (agent-scope fetch-add, one per workgroup) drawn by wave 0 at the START of its final pass, so that its round
+//         trip runs under the final QK^T / softmax / PV instead of after them; it is claimed after the loop and shared through
+//         LDS at the barrier the wave merge needs anyway.  The add is issued by inline asm (hipcc would wait for a returning
+//         atomic on the spot); build.py audits the emitted ISA: nothing touches the destination register between the add and
+//         the claiming wait;
+//     (b) the chunk's record: per output element the chunk-normalised value o_c and the chunk's log-sum-exp, as 8-byte
+//         {value, tag} granules.  Every workgroup but the holder of the last ticket stores its granules and EXITS: no drain,
+//         no flag, no second barrier;
+//     (c) the holder of the LAST ticket keeps its own record in registers, sweeps the other chunks' granules until every tag is
+//         set (they belong to workgroups that have drawn a ticket, i.e. that are resident and at most one pass from storing them:
+//         the wait cannot depend on an undispatched workgroup; the spin is bounded all the same and a give-up writes NaN), merges
+//         all chunks IN CHUNK ORDER (bitwise repeatable whoever merges), writes the output, stores ZERO back over every granule it
+//         consumed and returns the ticket to zero: between launches the workspace holds no set tag and no drawn ticket (the
+//         state the caller's one-time zero fill established), whatever shapes and chunk counts the launches had.
+//     No combine launch (-4.7 us per layer); against the round-1 form (record stores -> vmcnt(0) -> barrier -> ticket -> barrier ->
+//     record loads: three dependent memory round trips in the tail of every launch) one round trip remains.
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     // the operands on the way to the first DMA come first and flat: with -amdgpu-kernarg-preload-count they are in SGPRs when the
@@ -619,6 +644,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     void* const e_out = a.out;
     uint16_t* const e_out_packed = a.out_packed;
     const int e_out_f32 = a.out_f32, e_h = a.h;
+    const int live_chunks = min(NC, live_passes);
+    const int64_t pair = (int64_t)b * p_kvh + kh;
+    unsigned tk;                                              // wave 0, lane 0: what the ticket add returned (lands long after its issue)
+    asm volatile("v_mov_b32 %0, 0" : "=v"(tk));
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
         // first K image, then q, then the first V image: everything the K DMA needs arrived with the wave (preloaded arguments,
         // the block id), while q's pointer is still behind a kernarg load; the first wait below (q and K landed) counts on q
@@ -648,6 +677,23 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");      // q and this pass's K landed
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
+            }
+            // wave 0's final pass (no wave of the workgroup has more passes than wave 0): draw the workgroup's ticket NOW; the
+            // add's round trip runs under this pass's QK^T, softmax and PV and is claimed after the loop.  Lane 0 only (EXEC is
+            // narrowed inside the statement and restored: the MFMA code around it needs EXEC all ones).  It is one more
+            // vector-memory operation in flight, younger than this pass's V image: the V wait below counts it.
+            const bool draw = !has_next && wave == 0 && live_chunks > 1;          // wave-uniform
+            if (draw) {
+                unsigned long long exec_save;
+                asm volatile("s_nop 4\n\t"
+                             "s_mov_b64 %[sv], exec\n\t"
+                             "s_mov_b64 exec, 1\n\t"
+                             "s_nop 1\n\t"
+                             "global_atomic_add %[tk], %[off], %[one], %[base] sc0 ; NVH_TICKET_DRAW\n\t"
+                             "s_mov_b64 exec, %[sv]"
+                             : [tk] "+v"(tk), [sv] "=&s"(exec_save)
+                             : [off] "v"(0u), [one] "v"(1u), [base] "s"(e_counters + pair)
+                             : "memory");
             }
             const unsigned char* const lds_k = lds_w + buf * WAVE_BYTES;
             const unsigned char* const lds_v = lds_k + IMG;
@@ -704,6 +750,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             m_run = m_new;
             if (pass == split) NVH_STAMP(4);
             if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");   // this pass's V landed
+            else if (draw) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");               // ... the ticket add may still be in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (pass == split) NVH_STAMP(5);
             // ---- O^T += V^T P^T, P as hi + lo bf16
@@ -760,12 +807,15 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                 lds_ml[(wave * 2 + 1) * 16 + lq] = l_run;
             }
         }
+        if (wave == 0 && live_chunks > 1) {                   // wave-uniform: claim the ticket drawn in the final pass
+            asm volatile("s_waitcnt vmcnt(0) ; NVH_TICKET_CLAIM" : "+v"(tk)::"memory");
+            if (lane == 0) *lds_ticket = tk;
+        }
     }
     __syncthreads();
 
     // ---- merge the live waves (those with a live tile in the workgroup's first pass), then the live chunks
     const int n_waves = min(WAVES, (ctx - split * SPLIT + WT - 1) / WT);
-    const int live_chunks = min(NC, live_passes);
     constexpr int EPT = 16 * D / (MW * 64);                   // elements per thread when G == 16
     float Mv[EPT], Lv[EPT], Ov[EPT];
 #pragma unroll
@@ -798,77 +848,99 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         }
     }
     NVH_TSTAMP(1);
+    bool poisoned = false;
     if (live_chunks > 1) {
-        const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
-        float* const recs = e_ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
-        float* const mine = recs + (int64_t)split * rec;
+        // this chunk's record: o_c = O / L (chunk-normalised) and lse_c = max + log2(L), per output element
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + e * WAVES * 64;
-            if (idx < G * D) {
-                st_sc1(mine + idx, Ov[e]);
-                if (idx % D == 0) {
-                    st_sc1(mine + G * D + idx / D, Mv[e]);
-                    st_sc1(mine + G * D + G + idx / D, Lv[e]);
-                }
-            }
+            Ov[e] = Ov[e] / Lv[e];                             // L > 0: a live chunk holds at least one live token
+            Mv[e] = Mv[e] + fast_log2(Lv[e]);
         }
-        NVH_TSTAMP(2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        NVH_TSTAMP(3);
-        if (tid == 0) {
-            unsigned* const ctr = e_counters + (int64_t)b * p_kvh + kh;
-            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *lds_ticket = old;
-        }
-        __syncthreads();
-        NVH_TSTAMP(4);
-        if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
-        // records are requested CB at a time (every load of a batch in flight together); four chunks, the common shape of a
-        // full launch, are one batch of 12 loads per thread rather than an 8-wide batch with half of it repeated
-        auto merge_chunks = [&](auto cb_tag) {
-            constexpr int CB = decltype(cb_tag)::value;
+        constexpr unsigned tag = kGranuleTag;
+        const int rec = 2 * G * D;                            // granules per record: [element][o | lse]
+        u64* const recs = reinterpret_cast<u64*>(e_ws_acc) + pair * NC * rec;
+        const bool last = *lds_ticket == (unsigned)live_chunks - 1;          // workgroup-uniform
+        if (!last) {
+            u64* const mine = recs + (int64_t)split * rec;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int idx = tid + e * WAVES * 64;
                 if (idx < G * D) {
-                    const int g = idx / D;
-                    float M = -INFINITY, ov = 0.f, L = 0.f;
-                    for (int c0 = 0; c0 < live_chunks; c0 += CB) {
-                        float mv[CB], lv[CB], av[CB];
+                    st_granule(mine + 2 * idx, Ov[e], tag);
+                    st_granule(mine + 2 * idx + 1, Mv[e], tag);
+                }
+            }
+            NVH_TSTAMP(2);
+            return;                                            // whole workgroup; the stores complete on their own
+        }
+        NVH_TSTAMP(3);
+        // holder of the last ticket: every other live chunk has drawn its ticket, i.e. is past the start of its final pass.
+        // Records are requested CB chunks at a time (every load of a batch in flight together) and re-requested until all tags
+        // of the batch are set; own chunk from registers, merged in its chunk position.
+        constexpr int CB = 4;
+        constexpr unsigned kSpinLimit = 1u << 16;             // ~0.1 s of polling: a corrupted workspace ends in NaN, not in a hang
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = tid + e * WAVES * 64;
+            if (idx < G * D) {
+                float Mx = -INFINITY, W = 0.f, acc = 0.f;
+                for (int c0 = 0; c0 < live_chunks; c0 += CB) {
+                    float ov[CB], lv[CB];
+                    for (unsigned spins = 0;; ++spins) {
+                        u64 go[CB], gl[CB];
 #pragma unroll
                         for (int i = 0; i < CB; ++i) {
                             const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
-                            const float* r = recs + (int64_t)c * rec;
-                            mv[i] = ld_sc1(r + G * D + g);
-                            lv[i] = ld_sc1(r + G * D + G + g);
-                            av[i] = ld_sc1(r + idx);
+                            const u64* r = recs + (int64_t)c * rec + 2 * idx;
+                            go[i] = ld_granule(r);
+                            gl[i] = ld_granule(r + 1);
                         }
-                        float Mc = M;
+                        bool ok = true;
 #pragma unroll
-                        for (int i = 0; i < CB; ++i)
-                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, mv[i]);
-                        const float fo = fast_exp2(M - Mc);        // M = -inf on the first group -> 0
-                        ov *= fo;
-                        L *= fo;
+                        for (int i = 0; i < CB; ++i) {
+                            const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
+                            if (c == split) { ov[i] = Ov[e]; lv[i] = Mv[e]; continue; }
+                            ok &= (unsigned)(go[i] >> 32) == tag && (unsigned)(gl[i] >> 32) == tag;
+                            ov[i] = __builtin_bit_cast(float, (unsigned)go[i]);
+                            lv[i] = __builtin_bit_cast(float, (unsigned)gl[i]);
+                        }
+                        if (ok) {                               // consumed: the slots go back to "no tag set" for the next launch
 #pragma unroll
-                        for (int i = 0; i < CB; ++i)
-                            if (c0 + i < live_chunks) {
-                                const float f = fast_exp2(mv[i] - Mc);
-                                ov = fmaf(av[i], f, ov);
-                                L = fmaf(lv[i], f, L);
+                            for (int i = 0; i < CB; ++i) {
+                                const int c = c0 + i;
+                                if (c < live_chunks && c != split) {
+                                    u64* r = recs + (int64_t)c * rec + 2 * idx;
+                                    __hip_atomic_store(r, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store(r + 1, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
                             }
-                        M = Mc;
+                            break;
+                        }
+                        if (spins >= kSpinLimit) { poisoned = true; break; }
+                        __builtin_amdgcn_s_sleep(8);
                     }
-                    Lv[e] = L; Ov[e] = ov;
+                    float Mc = Mx;
+#pragma unroll
+                    for (int i = 0; i < CB; ++i)
+                        if (c0 + i < live_chunks) Mc = fmaxf(Mc, lv[i]);
+                    const float fo = fast_exp2(Mx - Mc);       // Mx = -inf on the first batch -> 0
+                    acc *= fo;
+                    W *= fo;
+#pragma unroll
+                    for (int i = 0; i < CB; ++i)
+                        if (c0 + i < live_chunks) {
+                            const float w = fast_exp2(lv[i] - Mc);
+                            acc = fmaf(ov[i], w, acc);
+                            W += w;
+                        }
+                    Mx = Mc;
                 }
+                Ov[e] = poisoned ? __builtin_nanf("") : acc;
+                Lv[e] = W;
             }
-        };
-        if (live_chunks <= 4) merge_chunks(std::integral_constant<int, 4>{});
-        else merge_chunks(std::integral_constant<int, 8>{});
+        }
         NVH_TSTAMP(5);
+        if (tid == 0) __hip_atomic_store(e_counters + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket of the pair is in
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -1003,10 +1075,12 @@ static int device_cus() {
 }
 
 // workgroups per (sequence, kv head): one wave of workgroups over the chip, at most one per pass; `forced` > 0 (the
-// variant entry point, tests and A/B runs) overrides the choice
+// variant entry point, tests and A/B runs) lowers the choice
 int decode_chunks(int batch, int kvh, int num_splits, int forced) {
-    const int cus = device_cus();
-    int c = forced > 0 ? forced : (cus + batch * kvh / 2) / (batch * kvh);
+    // never more workgroups than CUs (one workgroup per CU by its LDS footprint): a second round of workgroups costs far more than
+    // the pass imbalance it removes (round 1: 12.5 vs 9.7 us), and the holder of a pair's last ticket then never waits long
+    const int most = device_cus() / (batch * kvh);
+    int c = forced > 0 && forced < most ? forced : most;
     if (c < 1) c = 1;
     return c > num_splits ? num_splits : c;
 }

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import NVH_BF16, NVH_F32
 
-_workspaces: dict[int, torch.Tensor] = {}
+_workspaces: dict[tuple, torch.Tensor] = {}
 _retired_workspaces: list[torch.Tensor] = []
 
 
@@ -73,12 +73,16 @@ def decode_workspace_bytes(batch, num_heads, head_dim, max_blocks, block_size) -
     return int(_lib.load().nvh_paged_decode_workspace(batch, num_heads, head_dim, max_blocks, block_size))
 
 
-def reserve_workspace(device, nbytes: int) -> torch.Tensor:
+def reserve_workspace(device, nbytes: int, kind: str = "chunked") -> torch.Tensor:
     """Grow (never shrink) the per-device decode scratch.  Call before graph capture with the largest shape; all layers
-    share it (they run back to back on one stream).  ZERO-FILLED: its first 64 KiB are the arrival tickets of the chunked
-    decode kernel, which must read zero before the first launch and are returned to zero by every launch."""
+    share it (they run back to back on ONE stream — the reference runs one process per GPU and one stream per process;
+    callers that launch decode attention on several streams concurrently must pass their own `workspace=` per stream).
+    ZERO-FILLED: the chunk records of the decode kernel are self-validating granules whose tags must read "not set" before the
+    first launch; every launch stores zero back over what it consumed.  The split + combine variants (tests, A/B) keep plain
+    floats in their scratch and therefore get a buffer of their own (`kind`)."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
+    idx = (idx, kind)
     ws = _workspaces.get(idx)
     if ws is None or ws.numel() < nbytes:
         if ws is not None and torch.cuda.is_current_stream_capturing():
@@ -91,7 +95,7 @@ def reserve_workspace(device, nbytes: int) -> torch.Tensor:
     return ws
 
 
-def _decode_common(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype):
+def _decode_common(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype, workspace=None, kind="chunked"):
     squeeze = q.dim() == 4
     if squeeze:
         assert q.shape[1] == 1, "Decode stage should have seq_len=1"      # attention_sdpa.py:133
@@ -116,12 +120,16 @@ def _decode_common(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scal
         assert out.shape == (b, h, hd) and out.is_contiguous() and out.dtype == out_dtype
     max_blocks = block_table.shape[1]
     need = decode_workspace_bytes(b, h, hd, max_blocks, bs)
-    ws = reserve_workspace(q.device, need)
+    if workspace is not None:
+        assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.numel() >= need
+        ws = workspace
+    else:
+        ws = reserve_workspace(q.device, need, kind)
     return squeeze, q3, b, h, hd, kvh, bs, max_blocks, float(softmax_scale), out, ws
 
 
 def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale=None, causal=True,
-                            out=None, out_dtype=None, out_packed=None, variant=None, waves=0, chunks=0):
+                            out=None, out_dtype=None, out_packed=None, variant=None, waves=0, chunks=0, workspace=None):
     """Decode attention, drop-in for the call at attention.py:99-101.
 
     q [B, 1, H, D] (or [B, H, D]); caches [NB, bs, KVH, D]; cache_seqlens int32 [B] (0 -> zero row);
@@ -129,9 +137,11 @@ def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, sof
     sequence it has no effect.  Returns [B, 1, H, D] (or [B, H, D]).  out_packed: optional flat bf16 buffer of
     ceil(B/16)*16*H*D elements that also receives the result in MFMA-fragment order (pack_rows layout) for fused_linear.
     variant ("chunked" | "split_mfma" | "split_valu"), waves, chunks: tests / A-B only (nvh_paged_decode_variant); the module
-    path never passes them."""
+    path never passes them.  workspace: a caller-owned ZERO-FILLED uint8 buffer of decode_workspace_bytes() (one per stream
+    that may run decode attention concurrently); default: the per-device buffer of reserve_workspace()."""
     squeeze, q3, b, h, hd, kvh, bs, max_blocks, scale, out, ws = _decode_common(
-        q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype)
+        q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, out, out_dtype, workspace,
+        "split" if variant in ("split_mfma", "split_valu") else "chunked")
     tail = (q3.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_table.data_ptr(), cache_seqlens.data_ptr(), b, h, kvh, hd, bs,
             max_blocks, q3.stride(0), block_table.stride(0), scale, NVH_BF16, _out_code(out.dtype), ws.data_ptr(), ws.numel(), _stream())
     if variant is not None or waves or chunks:

@@ -57,7 +57,7 @@ def test_engine_greedy_tokens_graph_equals_eager(max_tokens):
     """End to end through the engine: prefill + decode steps of a 2-layer Qwen2-shaped model; the device-resident
     HIP-graph session (metadata advanced on the device, next step's embedding looked up by the arg-max launch) must produce
     exactly the tokens of the eager, host-metadata path (model_runner.py:278-303).  270 steps carry every sequence across a
-    block boundary (slot arithmetic of the device-side advance) and through hundreds of ticket resets."""
+    block boundary (slot arithmetic of the device-side advance) and through hundreds of generation changes of the attention hand-off."""
     from nanovllm_hip.engine.llm_engine import LLMEngine
     from nanovllm_hip.models.qwen import model_config
     cfg = model_config("Qwen2-0.5B", num_hidden_layers=2, vocab_size=2048)

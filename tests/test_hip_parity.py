@@ -654,3 +654,72 @@ def test_prefill_short_sequence_kernel(seed):
         outs[mode, waves] = o32
     for key in (("short", 8), ("short", 16)):                    # same arithmetic per (row, key tile); only the tile schedule differs
         assert (outs[key] - outs["tiled", 0]).abs().max().item() <= 2e-4
+
+
+# ------------------------------------------------------------------------------------------ the cross-workgroup hand-off, at its extremes
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,KVH,D,background", [(7, 1, 64, False), (7, 1, 64, True), (16, 1, 128, False), (4, 2, 128, True)])
+def test_chunk_handoff_extreme_geometry_under_graph_replay(H, KVH, D, background):
+    """The chunk hand-off (tagged granules, merger = chunk 0, generation advanced per launch) where it is widest: one or two
+    (sequence, kv head) pairs split over the most chunks the launch allows (16 at D = 64: four record batches per element), the
+    SAME captured launch replayed 320 times on the SAME workspace with a different query and a different context length every
+    time — so a record slot holds, at every replay, valid-looking granules of an EARLIER launch (other values, an older tag) —
+    and every replay compared with the oracle's answer for that (query, context).  Contexts cycle through 16, 9, 2 and 1 live
+    chunks, a ragged last pass, and 0 (padding row: no hand-off, zeros).  `background`: a second stream keeps the memory
+    system busy with copies meanwhile (uneven load: granules land late and out of order relative to the merger's sweeps)."""
+    from nanovllm_hip import ops
+    B, bs, width = 2 if KVH == 2 else 1, 256, 16
+    split = 256 if D == 64 else 128
+    rng = np.random.default_rng(77 + H + D)
+    gen = torch.Generator().manual_seed(78 + H + D)
+    nb = B * width + 2
+    kc = torch.randn(nb, bs, KVH, D, generator=gen).bfloat16()
+    vc = torch.randn(nb, bs, KVH, D, generator=gen).bfloat16()
+    bt = rng.permutation(nb)[: B * width].reshape(B, width).astype(np.int32)
+    ctx_pool = [16 * bs, 16 * bs - 1, 9 * split, 9 * split + 1, 2 * split, split + 17, split, 5, 1, 0, 3000, 2049]
+    cases = []
+    for i, c in enumerate(ctx_pool):
+        q = torch.randn(B, H, D, generator=gen).bfloat16()
+        ctxs = np.full(B, c, np.int32)
+        if B == 2:
+            ctxs[1] = ctx_pool[(i + 5) % len(ctx_pool)]                       # the two sequences never agree on the chunk count
+        exp = O.paged_decode(q.float().numpy(), kc.float().numpy(), vc.float().numpy(), ctxs, bt)
+        cases.append((q.cuda(), torch.from_numpy(ctxs).cuda(), exp))
+    kd, vd, btd = kc.cuda(), vc.cuda(), torch.from_numpy(bt).cuda()
+    q_s = torch.zeros(B, H, D, dtype=torch.bfloat16, device="cuda")
+    cl_s = torch.zeros(B, dtype=torch.int32, device="cuda")
+    out_s = torch.zeros(B, H, D, dtype=torch.float32, device="cuda")
+    ops.reserve_workspace("cuda", ops.decode_workspace_bytes(B, H, D, width, bs))
+    ops.flash_attn_with_kvcache(q_s, kd, vd, cl_s, btd, out=out_s, out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        ops.flash_attn_with_kvcache(q_s, kd, vd, cl_s, btd, out=out_s, out_dtype=torch.float32)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device="cuda") if background else None
+    order = rng.integers(0, len(cases), size=320)
+    outs = torch.empty(len(order), B, H, D, dtype=torch.float32, device="cuda")
+    for n, ci in enumerate(order):
+        q, cl, _ = cases[ci]
+        q_s.copy_(q)
+        cl_s.copy_(cl)
+        if background and n % 2 == 0:
+            with torch.cuda.stream(side):
+                junk[: 32 << 20].copy_(junk[32 << 20:])                      # ~64 MB of traffic racing the replay
+        graph.replay()
+        outs[n].copy_(out_s)
+    torch.cuda.synchronize()
+    got = outs.cpu().numpy()
+    assert np.isfinite(got).all(), "a merger gave up on its sweep (NaN marks a bounded-spin timeout)"
+    worst = 0.0
+    for n, ci in enumerate(order):
+        err = np.abs(got[n] - cases[ci][2]).max()
+        worst = max(worst, err)
+        assert err <= ATOL, f"replay {n} (case {ci}, ctx {cases[ci][1].tolist()}): max abs err {err:.3e}"
+    # bitwise repeatability: the same (query, context) gives the same bits whenever it is replayed
+    first = {}
+    for n, ci in enumerate(order):
+        if ci in first:
+            assert np.array_equal(got[n], got[first[ci]])
+        else:
+            first[ci] = n
