@@ -61,34 +61,93 @@ def _compile(src, asm, extra=(), obj_dir=None):
 def audit_ticket_registers(asm_path):
     """The decode kernel draws its arrival ticket with an inline-asm returning atomic whose result lands long after the statement
     (csrc/paged_decode.hip, NVH_TICKET_DRAW) and claims it behind an explicit wait (NVH_TICKET_CLAIM).  hipcc does not know the
-    register is in flight: this audit proves, on the ISA that was actually emitted, that NO instruction between the two
-    markers names the destination VGPR (alone or inside a register range).  Returns the number of draw sites checked."""
+    register is in flight: this audit proves, on the ISA that was actually emitted, that NO instruction on any control-flow path
+    from the draw to the claim names the destination VGPR (alone or inside a register range).  Paths are taken from the
+    function's own branch structure: blocks reachable from the draw that can still reach the claim (a block that only leads to
+    s_endpgm without claiming — e.g. the single-chunk epilogue, where the register is dead — is not on such a path).
+    Returns the number of draw sites checked."""
     import re
-    lines = open(asm_path).read().split("\n")
+    text = open(asm_path).read().split("\n")
+    # ---- split into functions, then into basic blocks
+    funcs, cur = [], None
+    for n, line in enumerate(text):
+        if re.match(r"^[A-Za-z_][\w$.]*:\s*(;.*)?$", line) and not line.startswith(".L"):
+            cur = []
+            funcs.append(cur)
+        if cur is not None:
+            cur.append((n + 1, line))
     checked = 0
-    i = 0
-    while i < len(lines):
-        if "NVH_TICKET_DRAW" in lines[i] and "global_atomic_add" in lines[i]:
-            m = re.search(r"global_atomic_add\s+v(\d+)\s*,", lines[i])
+    for fn in funcs:
+        if not any("NVH_TICKET_DRAW" in l for _, l in fn):
+            continue
+        blocks, label_of = [[]], {}
+        for n, line in fn:
+            m = re.match(r"^(\.LBB\d+_\d+):", line)
+            if m:
+                blocks.append([])
+                label_of[m.group(1)] = len(blocks) - 1
+                continue
+            code = line.split(";")[0].strip() if not line.strip().startswith(";;") else ""
+            if not code or code.startswith("."):
+                if "NVH_TICKET" not in line:
+                    continue
+            blocks[-1].append((n, line))
+            if re.match(r"s_(branch|cbranch_\w+|endpgm|setpc_b64)\b", code):
+                blocks.append([])
+        succ = [set() for _ in blocks]
+        for i, blk in enumerate(blocks):
+            last = blk[-1][1].split(";")[0].strip() if blk else ""
+            m = re.match(r"s_(branch|cbranch_\w+)\s+(\.LBB\d+_\d+)", last)
+            if m:
+                succ[i].add(label_of[m.group(2)])
+            if not re.match(r"s_(branch|endpgm|setpc_b64)\b", last) and i + 1 < len(blocks):
+                succ[i].add(i + 1)
+        pred = [set() for _ in blocks]
+        for i, ss in enumerate(succ):
+            for j in ss:
+                pred[j].add(i)
+
+        def reach(starts, edges):
+            seen, todo = set(), list(starts)
+            while todo:
+                x = todo.pop()
+                if x not in seen:
+                    seen.add(x)
+                    todo.extend(edges[x])
+            return seen
+
+        def names(code, reg):
+            if re.search(rf"\bv{reg}\b", code):
+                return True
+            return any(int(a) <= reg <= int(b) for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code))
+
+        draws = [(i, k) for i, blk in enumerate(blocks) for k, (_, l) in enumerate(blk) if "NVH_TICKET_DRAW" in l]
+        claims = [(i, k) for i, blk in enumerate(blocks) for k, (_, l) in enumerate(blk) if "NVH_TICKET_CLAIM" in l]
+        if not claims:
+            raise RuntimeError(f"{asm_path}: a ticket is drawn at line {blocks[draws[0][0]][draws[0][1]][0]} but never claimed")
+        can_claim = reach([i for i, _ in claims], pred)               # blocks from which a claim is reachable (claim blocks included)
+        for di, dk in draws:
+            n0, l0 = blocks[di][dk]
+            m = re.search(r"global_atomic_add\s+v(\d+)\s*,", l0)
             if not m:
-                raise RuntimeError(f"{asm_path}:{i + 1}: cannot parse the ticket draw: {lines[i].strip()}")
+                raise RuntimeError(f"{asm_path}:{n0}: cannot parse the ticket draw: {l0.strip()}")
             reg = int(m.group(1))
-            j = i + 1
-            while j < len(lines) and "NVH_TICKET_CLAIM" not in lines[j]:
-                code = lines[j].split(";")[0]
-                if ".Lfunc_end" in code or code.strip().startswith(".size"):
-                    raise RuntimeError(f"{asm_path}:{i + 1}: ticket drawn but never claimed before the function ends")
-                hit = re.search(rf"\bv{reg}\b", code) is not None
-                for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code):
-                    hit = hit or int(a) <= reg <= int(b)
-                if hit and not code.strip().startswith(("s_mov_b64 exec", ";;")):
-                    raise RuntimeError(f"{asm_path}:{j + 1}: v{reg} (ticket in flight since line {i + 1}) is touched before the claim: {lines[j].strip()}")
-                j += 1
-            if j == len(lines):
-                raise RuntimeError(f"{asm_path}:{i + 1}: ticket drawn but no NVH_TICKET_CLAIM follows")
+            after = reach(succ[di], succ)                              # blocks entered after the draw block
+            on_path = (after & can_claim) - {i for i, _ in claims}
+            spans = [blocks[di][dk + 1:]] + [blocks[i] for i in sorted(on_path) if i != di]
+            if di in after and di in can_claim:                        # the draw sits in a loop that can come round to it
+                spans.append(blocks[di][:dk])
+            for ci, ck in claims:
+                if ci in after or ci == di:
+                    spans.append(blocks[ci][:ck] if ci != di else [])
+            if di not in can_claim:
+                raise RuntimeError(f"{asm_path}:{n0}: no claim is reachable from this draw")
+            for span in spans:
+                for n, line in span:
+                    code = line.split(";")[0]
+                    if names(code, reg) and "NVH_TICKET" not in line:
+                        raise RuntimeError(f"{asm_path}:{n}: v{reg} (ticket in flight since line {n0}) is touched before the claim: {line.strip()}")
             checked += 1
-            i = j
-        i += 1
     if checked == 0:
         raise RuntimeError(f"{asm_path}: no NVH_TICKET_DRAW site found (the audit is stale)")
     return checked

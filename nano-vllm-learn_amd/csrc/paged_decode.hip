@@ -527,22 +527,22 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //   * each wave owns two K + V image pairs (double buffer) and runs the online softmax over its passes without any
 //     workgroup barrier: pass p+1's LDS-DMA is issued before pass p is consumed, behind counted vmcnt waits.
 //   * the waves merge through LDS once.  With more than one live chunk, the hand-off to the workgroup that writes the output is
-//     (a) a TICKET (agent-scope fetch-add, one per workgroup) drawn by wave 0 at the START of its final pass, so that its round
-//         trip runs under the final QK^T / softmax / PV instead of after them; it is claimed after the loop and shared through
-//         LDS at the barrier the wave merge needs anyway.  The add is issued by inline asm (hipcc would wait for a returning
-//         atomic on the spot); build.py audits the emitted ISA: nothing touches the destination register between the add and
-//         the claiming wait;
-//     (b) the chunk's record: per output element the chunk-normalised value o_c and the chunk's log-sum-exp, as 8-byte
-//         {value, tag} granules.  Every workgroup but the holder of the last ticket stores its granules and EXITS: no drain,
-//         no flag, no second barrier;
-//     (c) the holder of the LAST ticket keeps its own record in registers, sweeps the other chunks' granules until every tag is
-//         set (they belong to workgroups that have drawn a ticket, i.e. that are resident and at most one pass from storing them:
-//         the wait cannot depend on an undispatched workgroup; the spin is bounded all the same and a give-up writes NaN), merges
-//         all chunks IN CHUNK ORDER (bitwise repeatable whoever merges), writes the output, stores ZERO back over every granule it
-//         consumed and returns the ticket to zero: between launches the workspace holds no set tag and no drawn ticket (the
-//         state the caller's one-time zero fill established), whatever shapes and chunk counts the launches had.
+//     (a) a TICKET (agent-scope fetch-add, one per workgroup) drawn right after the barrier that ends the pass loop, so that its
+//         round trip runs UNDER the in-LDS wave merge and the record stores instead of after them.  The add is issued by inline
+//         asm (hipcc would wait for a returning atomic on the spot); build.py audits the emitted ISA: nothing touches the
+//         destination register between the add and the claiming wait;
+//     (b) the chunk's record: per output element the chunk-normalised value o_c, per head the chunk's log-sum-exp, as 8-byte
+//         {value, tag} granules, stored by EVERY live chunk as soon as the wave merge has produced them: no drain, no flag;
+//     (c) the ticket is claimed and shared through LDS; every workgroup but the holder of the LAST ticket exits.  That one
+//         sweeps the other chunks' granules (their stores were issued about half a round trip after their tickets, all drawn
+//         before the last one: in practice every tag is set at the first sweep; the sweep repeats until they are, bounded, and a
+//         give-up writes NaN — it waits only on workgroups that have drawn a ticket, i.e. that are resident and have a few
+//         hundred instructions left, never on an undispatched one), merges all chunks IN CHUNK ORDER (bitwise repeatable
+//         whoever merges), writes the output, stores ZERO back over every granule of the pair and returns the ticket to zero:
+//         between launches the workspace holds no set tag and no drawn ticket (the state the caller's one-time zero fill
+//         established), whatever shapes and chunk counts the launches had.
 //     No combine launch (-4.7 us per layer); against the round-1 form (record stores -> vmcnt(0) -> barrier -> ticket -> barrier ->
-//     record loads: three dependent memory round trips in the tail of every launch) one round trip remains.
+//     record loads: three dependent memory round trips after the wave merge) two remain, one of them under the wave merge.
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     // the operands on the way to the first DMA come first and flat: with -amdgpu-kernarg-preload-count they are in SGPRs when the
@@ -646,8 +646,8 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     const int e_out_f32 = a.out_f32, e_h = a.h;
     const int live_chunks = min(NC, live_passes);
     const int64_t pair = (int64_t)b * p_kvh + kh;
-    unsigned tk;                                              // wave 0, lane 0: what the ticket add returned (lands long after its issue)
-    asm volatile("v_mov_b32 %0, 0" : "=v"(tk));
+    constexpr unsigned kTicketUnset = 0xffffffffu;
+    if (tid == 0) *lds_ticket = kTicketUnset;                 // (a barrier lies between this and every reader)
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
         // first K image, then q, then the first V image: everything the K DMA needs arrived with the wave (preloaded arguments,
         // the block id), while q's pointer is still behind a kernarg load; the first wait below (q and K landed) counts on q
@@ -677,23 +677,6 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NI) : "memory");      // q and this pass's K landed
             } else {
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-            }
-            // wave 0's final pass (no wave of the workgroup has more passes than wave 0): draw the workgroup's ticket NOW; the
-            // add's round trip runs under this pass's QK^T, softmax and PV and is claimed after the loop.  Lane 0 only (EXEC is
-            // narrowed inside the statement and restored: the MFMA code around it needs EXEC all ones).  It is one more
-            // vector-memory operation in flight, younger than this pass's V image: the V wait below counts it.
-            const bool draw = !has_next && wave == 0 && live_chunks > 1;          // wave-uniform
-            if (draw) {
-                unsigned long long exec_save;
-                asm volatile("s_nop 4\n\t"
-                             "s_mov_b64 %[sv], exec\n\t"
-                             "s_mov_b64 exec, 1\n\t"
-                             "s_nop 1\n\t"
-                             "global_atomic_add %[tk], %[off], %[one], %[base] sc0 ; NVH_TICKET_DRAW\n\t"
-                             "s_mov_b64 exec, %[sv]"
-                             : [tk] "+v"(tk), [sv] "=&s"(exec_save)
-                             : [off] "v"(0u), [one] "v"(1u), [base] "s"(e_counters + pair)
-                             : "memory");
             }
             const unsigned char* const lds_k = lds_w + buf * WAVE_BYTES;
             const unsigned char* const lds_v = lds_k + IMG;
@@ -750,7 +733,6 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             m_run = m_new;
             if (pass == split) NVH_STAMP(4);
             if (has_next) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");   // this pass's V landed
-            else if (draw) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");               // ... the ticket add may still be in flight
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (pass == split) NVH_STAMP(5);
             // ---- O^T += V^T P^T, P as hi + lo bf16
@@ -807,12 +789,25 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                 lds_ml[(wave * 2 + 1) * 16 + lq] = l_run;
             }
         }
-        if (wave == 0 && live_chunks > 1) {                   // wave-uniform: claim the ticket drawn in the final pass
-            asm volatile("s_waitcnt vmcnt(0) ; NVH_TICKET_CLAIM" : "+v"(tk)::"memory");
-            if (lane == 0) *lds_ticket = tk;
-        }
     }
     __syncthreads();
+    // the workgroup's ticket, drawn NOW by the last wave's lane 0 (EXEC is narrowed inside the statement and restored): the add's
+    // round trip runs under the wave merge and the record stores below and is claimed after them
+    const bool drawer = wave == WAVES - 1 && live_chunks > 1;                     // wave-uniform
+    unsigned tk;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(tk));
+    if (drawer) {
+        unsigned long long exec_save;
+        asm volatile("s_nop 4\n\t"
+                     "s_mov_b64 %[sv], exec\n\t"
+                     "s_mov_b64 exec, 1\n\t"
+                     "s_nop 1\n\t"
+                     "global_atomic_add %[tk], %[off], %[one], %[base] sc0 ; NVH_TICKET_DRAW\n\t"
+                     "s_mov_b64 exec, %[sv]"
+                     : [tk] "+v"(tk), [sv] "=&s"(exec_save)
+                     : [off] "v"(0u), [one] "v"(1u), [base] "s"(e_counters + pair)
+                     : "memory");
+    }
 
     // ---- merge the live waves (those with a live tile in the workgroup's first pass), then the live chunks
     const int n_waves = min(WAVES, (ctx - split * SPLIT + WT - 1) / WT);
@@ -848,98 +843,106 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         }
     }
     NVH_TSTAMP(1);
-    bool poisoned = false;
     if (live_chunks > 1) {
-        // this chunk's record: o_c = O / L (chunk-normalised) and lse_c = max + log2(L), per output element
+        // this chunk's record: o_c = O / L (chunk-normalised) per output element and lse_c = max + log2(L) per head
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             Ov[e] = Ov[e] / Lv[e];                             // L > 0: a live chunk holds at least one live token
             Mv[e] = Mv[e] + fast_log2(Lv[e]);
         }
         constexpr unsigned tag = kGranuleTag;
-        const int rec = 2 * G * D;                            // granules per record: [element][o | lse]
+        const int rec = 16 + G * D;                           // granules per record: [16 heads: lse][G*D elements: o]
         u64* const recs = reinterpret_cast<u64*>(e_ws_acc) + pair * NC * rec;
-        const bool last = *lds_ticket == (unsigned)live_chunks - 1;          // workgroup-uniform
-        if (!last) {
+        {
             u64* const mine = recs + (int64_t)split * rec;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int idx = tid + e * WAVES * 64;
                 if (idx < G * D) {
-                    st_granule(mine + 2 * idx, Ov[e], tag);
-                    st_granule(mine + 2 * idx + 1, Mv[e], tag);
+                    st_granule(mine + 16 + idx, Ov[e], tag);
+                    if (idx % D == 0) st_granule(mine + idx / D, Mv[e], tag);
                 }
             }
-            NVH_TSTAMP(2);
-            return;                                            // whole workgroup; the stores complete on their own
         }
+        NVH_TSTAMP(2);
+        if (drawer) {                                          // claim: the add (and this wave's stores) have come back
+            asm volatile("s_waitcnt vmcnt(0) ; NVH_TICKET_CLAIM" : "+v"(tk)::"memory");
+            if (lane == 0) __hip_atomic_store(lds_ticket, tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        unsigned ticket;
+        while ((ticket = __hip_atomic_load(lds_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kTicketUnset) __builtin_amdgcn_s_sleep(1);
+        if (ticket != (unsigned)live_chunks - 1) return;       // workgroup-uniform: not the last one in
         NVH_TSTAMP(3);
-        // holder of the last ticket: every other live chunk has drawn its ticket, i.e. is past the start of its final pass.
-        // Records are requested CB chunks at a time (every load of a batch in flight together) and re-requested until all tags
-        // of the batch are set; own chunk from registers, merged in its chunk position.
-        constexpr int CB = 4;
-        constexpr unsigned kSpinLimit = 1u << 16;             // ~0.1 s of polling: a corrupted workspace ends in NaN, not in a hang
+        // holder of the last ticket.  One ATTEMPT = every granule it needs requested with no dependence between the requests (the
+        // compiler keeps them in flight together), merged speculatively in chunk order while a flag collects the tags; the
+        // attempt repeats only if some tag was not set yet.
+        constexpr unsigned kSpinLimit = 1u << 15;             // ~0.1 s: a corrupted workspace ends in NaN, not in a hang
+        bool ok = false;
+        float accv[EPT], Wv[EPT];
+        for (unsigned spins = 0; !ok; ++spins) {
+            ok = true;
+#pragma unroll
+            for (int e = 0; e < EPT; ++e) {
+                const int idx = tid + e * WAVES * 64;
+                accv[e] = 0.f; Wv[e] = 1.f;
+                if (idx < G * D) {
+                    const int g = idx / D;
+                    float Mx = -INFINITY, W = 0.f, acc = 0.f;
+                    constexpr int CB = 4;
+                    for (int c0 = 0; c0 < live_chunks; c0 += CB) {
+                        float ov[CB], lv[CB];
+#pragma unroll
+                        for (int i = 0; i < CB; ++i) {
+                            const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
+                            const u64* r = recs + (int64_t)c * rec;
+                            const u64 go = ld_granule(r + 16 + idx), gl = ld_granule(r + g);
+                            const bool own = c == split;       // own record from registers (its stores may still be in flight)
+                            ok &= own || ((unsigned)(go >> 32) == tag && (unsigned)(gl >> 32) == tag);
+                            ov[i] = own ? Ov[e] : __builtin_bit_cast(float, (unsigned)go);
+                            lv[i] = own ? Mv[e] : __builtin_bit_cast(float, (unsigned)gl);
+                        }
+                        float Mc = Mx;
+#pragma unroll
+                        for (int i = 0; i < CB; ++i)
+                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, lv[i]);
+                        const float fo = fast_exp2(Mx - Mc);   // Mx = -inf on the first batch -> 0
+                        acc *= fo;
+                        W *= fo;
+#pragma unroll
+                        for (int i = 0; i < CB; ++i)
+                            if (c0 + i < live_chunks) {
+                                const float w = fast_exp2(lv[i] - Mc);
+                                acc = fmaf(ov[i], w, acc);
+                                W += w;
+                            }
+                        Mx = Mc;
+                    }
+                    accv[e] = acc; Wv[e] = W;
+                }
+            }
+            if (!ok) {
+                if (spins >= kSpinLimit) break;
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            Ov[e] = ok ? accv[e] : __builtin_nanf("");
+            Lv[e] = Wv[e];
+        }
+        NVH_TSTAMP(5);
+        // the workspace as the next launch expects it: no tag set (own record included: same-address stores of one lane stay in
+        // order), no ticket drawn
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
             const int idx = tid + e * WAVES * 64;
-            if (idx < G * D) {
-                float Mx = -INFINITY, W = 0.f, acc = 0.f;
-                for (int c0 = 0; c0 < live_chunks; c0 += CB) {
-                    float ov[CB], lv[CB];
-                    for (unsigned spins = 0;; ++spins) {
-                        u64 go[CB], gl[CB];
-#pragma unroll
-                        for (int i = 0; i < CB; ++i) {
-                            const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
-                            const u64* r = recs + (int64_t)c * rec + 2 * idx;
-                            go[i] = ld_granule(r);
-                            gl[i] = ld_granule(r + 1);
-                        }
-                        bool ok = true;
-#pragma unroll
-                        for (int i = 0; i < CB; ++i) {
-                            const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
-                            if (c == split) { ov[i] = Ov[e]; lv[i] = Mv[e]; continue; }
-                            ok &= (unsigned)(go[i] >> 32) == tag && (unsigned)(gl[i] >> 32) == tag;
-                            ov[i] = __builtin_bit_cast(float, (unsigned)go[i]);
-                            lv[i] = __builtin_bit_cast(float, (unsigned)gl[i]);
-                        }
-                        if (ok) {                               // consumed: the slots go back to "no tag set" for the next launch
-#pragma unroll
-                            for (int i = 0; i < CB; ++i) {
-                                const int c = c0 + i;
-                                if (c < live_chunks && c != split) {
-                                    u64* r = recs + (int64_t)c * rec + 2 * idx;
-                                    __hip_atomic_store(r, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    __hip_atomic_store(r + 1, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                }
-                            }
-                            break;
-                        }
-                        if (spins >= kSpinLimit) { poisoned = true; break; }
-                        __builtin_amdgcn_s_sleep(8);
-                    }
-                    float Mc = Mx;
-#pragma unroll
-                    for (int i = 0; i < CB; ++i)
-                        if (c0 + i < live_chunks) Mc = fmaxf(Mc, lv[i]);
-                    const float fo = fast_exp2(Mx - Mc);       // Mx = -inf on the first batch -> 0
-                    acc *= fo;
-                    W *= fo;
-#pragma unroll
-                    for (int i = 0; i < CB; ++i)
-                        if (c0 + i < live_chunks) {
-                            const float w = fast_exp2(lv[i] - Mc);
-                            acc = fmaf(ov[i], w, acc);
-                            W += w;
-                        }
-                    Mx = Mc;
+            if (idx < G * D)
+                for (int c = 0; c < live_chunks; ++c) {
+                    u64* r = recs + (int64_t)c * rec;
+                    __hip_atomic_store(r + 16 + idx, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (idx % D == 0) __hip_atomic_store(r + idx / D, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                Ov[e] = poisoned ? __builtin_nanf("") : acc;
-                Lv[e] = W;
-            }
         }
-        NVH_TSTAMP(5);
         if (tid == 0) __hip_atomic_store(e_counters + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket of the pair is in
     }
 #pragma unroll
