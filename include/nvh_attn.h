@@ -66,11 +66,11 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
 
 /*
  * Bytes of caller-owned scratch nvh_paged_decode needs; a pure function of the static shapes so it can be
- * allocated once before graph capture.  Layout: a fixed 64 KiB header of arrival tickets (one uint32 per (sequence, kv
- * head)), then the records of the context chunks (8-byte {value, tag} granules).  The caller ZERO-FILLS the buffer once
- * (hipMemset / torch.zeros); every launch returns its tickets to zero and stores zero back over the granules it consumed,
- * so the buffer is reusable across calls, shapes and graph replays without further clearing.  ONE launch at a time per workspace: calls that may run concurrently (different streams)
- * need a workspace each; a launch that was aborted mid-flight leaves the header undefined (zero-fill it again).
+ * allocated once before graph capture.  Layout: a fixed 64 KiB header of arrival tickets (one uint32 per
+ * (sequence, kv head)), then the partial records of the context chunks.  The caller ZERO-FILLS the buffer once
+ * (hipMemset / torch.zeros); every launch returns its tickets to zero, so the buffer is reusable across calls,
+ * shapes and graph replays without further clearing.  ONE launch at a time per workspace: calls that may run concurrently
+ * (different streams) need a workspace each; a launch that was aborted mid-flight leaves the tickets undefined (zero-fill again).
  */
 size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int block_size);
 

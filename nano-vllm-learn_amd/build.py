@@ -58,108 +58,6 @@ def _compile(src, asm, extra=(), obj_dir=None):
     return obj
 
 
-def audit_ticket_registers(asm_path):
-    """The decode kernel draws its arrival ticket with an inline-asm returning atomic whose result lands long after the statement
-    (csrc/paged_decode.hip, NVH_TICKET_DRAW) and claims it behind an explicit wait (NVH_TICKET_CLAIM).  hipcc does not know the
-    register is in flight: this audit proves, on the ISA that was actually emitted, that NO instruction on any control-flow path
-    from the draw to the claim names the destination VGPR (alone or inside a register range).  Paths are taken from the
-    function's own branch structure: blocks reachable from the draw that can still reach the claim (a block that only leads to
-    s_endpgm without claiming — e.g. the single-chunk epilogue, where the register is dead — is not on such a path).
-    Returns the number of draw sites checked."""
-    import re
-    text = open(asm_path).read().split("\n")
-    # ---- split into functions, then into basic blocks
-    funcs, cur = [], None
-    for n, line in enumerate(text):
-        if re.match(r"^[A-Za-z_][\w$.]*:\s*(;.*)?$", line) and not line.startswith(".L"):
-            cur = []
-            funcs.append(cur)
-        if cur is not None:
-            cur.append((n + 1, line))
-    checked = 0
-    for fn in funcs:
-        if not any("NVH_TICKET_DRAW" in l for _, l in fn):
-            continue
-        blocks, label_of = [[]], {}
-        for n, line in fn:
-            m = re.match(r"^(\.LBB\d+_\d+):", line)
-            if m:
-                blocks.append([])
-                label_of[m.group(1)] = len(blocks) - 1
-                continue
-            code = line.split(";")[0].strip() if not line.strip().startswith(";;") else ""
-            if not code or code.startswith("."):
-                if "NVH_TICKET" not in line:
-                    continue
-            blocks[-1].append((n, line))
-            if re.match(r"s_(branch|cbranch_\w+|endpgm|setpc_b64)\b", code):
-                blocks.append([])
-        succ = [set() for _ in blocks]
-        for i, blk in enumerate(blocks):
-            last = blk[-1][1].split(";")[0].strip() if blk else ""
-            m = re.match(r"s_(branch|cbranch_\w+)\s+(\.LBB\d+_\d+)", last)
-            if m:
-                succ[i].add(label_of[m.group(2)])
-            if not re.match(r"s_(branch|endpgm|setpc_b64)\b", last) and i + 1 < len(blocks):
-                succ[i].add(i + 1)
-        pred = [set() for _ in blocks]
-        for i, ss in enumerate(succ):
-            for j in ss:
-                pred[j].add(i)
-
-        def reach(starts, edges):
-            seen, todo = set(), list(starts)
-            while todo:
-                x = todo.pop()
-                if x not in seen:
-                    seen.add(x)
-                    todo.extend(edges[x])
-            return seen
-
-        def names(code, reg):
-            if re.search(rf"\bv{reg}\b", code):
-                return True
-            return any(int(a) <= reg <= int(b) for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", code))
-
-        draws = [(i, k) for i, blk in enumerate(blocks) for k, (_, l) in enumerate(blk) if "NVH_TICKET_DRAW" in l]
-        claims = [(i, k) for i, blk in enumerate(blocks) for k, (_, l) in enumerate(blk) if "NVH_TICKET_CLAIM" in l]
-        if not claims:
-            raise RuntimeError(f"{asm_path}: a ticket is drawn at line {blocks[draws[0][0]][draws[0][1]][0]} but never claimed")
-        can_claim = reach([i for i, _ in claims], pred)               # blocks from which a claim is reachable (claim blocks included)
-        for di, dk in draws:
-            n0, l0 = blocks[di][dk]
-            m = re.search(r"global_atomic_add\s+v(\d+)\s*,", l0)
-            if not m:
-                raise RuntimeError(f"{asm_path}:{n0}: cannot parse the ticket draw: {l0.strip()}")
-            reg = int(m.group(1))
-            after = reach(succ[di], succ)                              # blocks entered after the draw block
-            on_path = (after & can_claim) - {i for i, _ in claims}
-            spans = [blocks[di][dk + 1:]] + [blocks[i] for i in sorted(on_path) if i != di]
-            if di in after and di in can_claim:                        # the draw sits in a loop that can come round to it
-                spans.append(blocks[di][:dk])
-            for ci, ck in claims:
-                if ci in after or ci == di:
-                    spans.append(blocks[ci][:ck] if ci != di else [])
-            if di not in can_claim:
-                raise RuntimeError(f"{asm_path}:{n0}: no claim is reachable from this draw")
-            for span in spans:
-                for n, line in span:
-                    code = line.split(";")[0]
-                    if names(code, reg) and "NVH_TICKET" not in line:
-                        raise RuntimeError(f"{asm_path}:{n}: v{reg} (ticket in flight since line {n0}) is touched before the claim: {line.strip()}")
-            checked += 1
-    if checked == 0:
-        raise RuntimeError(f"{asm_path}: no NVH_TICKET_DRAW site found (the audit is stale)")
-    return checked
-
-
-def _emit_asm(src):
-    flags = [*FLAGS, *FILE_FLAGS.get(src, [])]
-    out = os.path.join(OBJ_DIR, src.replace(".hip", ".audit.s"))
-    subprocess.run([HIPCC, *flags, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", out], check=True)
-    return out
-
-
 def build(force=False, asm=False, verbose=True):
     """Compile every HIP source for gfx950 and link libnvh_attn.so.  Returns the library path."""
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -173,11 +71,7 @@ def build(force=False, asm=False, verbose=True):
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; set HIPCC")
     with ThreadPoolExecutor(max_workers=4) as ex:
-        audit = ex.submit(_emit_asm, "paged_decode.hip")          # same flags as the object: the ISA the library ships
         objs = list(ex.map(lambda s: _compile(s, asm), SOURCES))
-        n = audit_ticket_registers(audit.result())
-    if verbose:
-        print(f"[nvh build] ISA audit: {n} ticket draw sites, destination register untouched until the claim")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], check=True)
     with open(stamp, "w") as f:
         f.write(digest)

@@ -83,7 +83,7 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
                                 k_row_stride, v_row_stride, (hipStream_t)stream);
 }
 
-static constexpr size_t kDecodeTicketBytes = 65536;       // header: 16384 arrival tickets (uint32), one per (sequence, kv head)
+static constexpr size_t kDecodeTicketBytes = 65536;       // 16384 tickets
 
 static int decode_num_splits(int hd, int max_blocks, int block_size) {
     const int split = decode_split_tokens(hd);
@@ -95,9 +95,9 @@ static int decode_num_splits(int hd, int max_blocks, int block_size) {
 size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int block_size) {
     if (batch <= 0 || h <= 0 || (hd != 64 && hd != 128) || max_blocks <= 0 || block_size <= 0) return 0;
     const size_t parts = (size_t)batch * h * decode_num_splits(hd, max_blocks, block_size);
-    // a fixed header of arrival tickets (one per (sequence, kv head); the SAME bytes whatever the shape), then the chunk records: per (sequence, head, chunk) hd
-    // elements x two 8-byte {value, tag} granules (the split + combine variants keep their hd + 2 floats in the same region)
-    return kDecodeTicketBytes + parts * (size_t)hd * 16;
+    // a fixed header of arrival tickets (one per (sequence, kv head); the SAME bytes whatever the shape, so that one
+    // workspace serves calls of different shapes), then the partial records
+    return kDecodeTicketBytes + parts * (size_t)(hd + 2) * sizeof(float);
 }
 
 static int paged_decode_impl(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,

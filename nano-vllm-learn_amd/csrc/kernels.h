@@ -24,8 +24,8 @@ struct DecodeArgs {
     float scale_log2;            // softmax scale * log2(e)
     int out_f32;
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
-    // chunked kernel (default): chunk records [B*KVH][chunks][G*D][o | lse] as 8-byte {value, tag} granules alias ws_acc
-    unsigned* counters;          // [B*KVH] arrival tickets of the pairs split over several workgroups: zero before the launch, left zero by it
+    // chunked kernel (default): partial records [B*KVH][chunks][G*(D+2)] fp32 alias ws_acc; arrival tickets per (b, kv head)
+    unsigned* counters;          // [B*KVH], zero before the launch, left zero by it
     int chunks;                  // workgroups per (sequence, kv head); passes are dealt to them round-robin
     uint16_t* out_packed;        // nullable: bf16 output also in MFMA-fragment order [ceil(B/16)][H*D/32][64][8] (pack_index)
     int impl;                    // 0 chunked MFMA (default), 1 split MFMA + combine, 2 split VALU + combine (nvh_paged_decode_variant)

@@ -37,6 +37,10 @@
 #include "common.h"
 #include "kernels.h"
 
+#ifndef NVH_D128_WAVES
+#define NVH_D128_WAVES 8     // waves per workgroup of the chunked kernel at head_dim 128 when the caller does not choose (4 or 8)
+#endif
+
 namespace nvh {
 
 namespace {
@@ -326,19 +330,6 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
     return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-// Chunk records of the chunked kernel travel as self-validating 8-byte granules {value, tag}: ONE naturally aligned 8-byte
-// write-through store per granule (relaxed agent-scope atomic store = global_store_dwordx2 sc1), read back by relaxed agent-scope
-// 8-byte loads (global_load_dwordx2 sc1, past the reader's L1).  A reader that sees the launch's tag sees the value written with
-// it; no ordering between different granules is needed, hence no store drain, no flag and no fence.
-// The tag is a NaN bit pattern no partial result carries (the split + combine variants keep plain floats in the same region).
-typedef unsigned long long u64;
-constexpr unsigned kGranuleTag = 0xFFD5A1ECu;
-__device__ __forceinline__ void st_granule(u64* p, float v, unsigned tag) {
-    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ u64 ld_granule(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
-
 template <int D>
 __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const DecodeArgs a, const int G) {
     using geo = MGeo<D>;
@@ -526,23 +517,11 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //     latency, merge, epilogue) are paid once per 2-8 passes instead of once per pass.
 //   * each wave owns two K + V image pairs (double buffer) and runs the online softmax over its passes without any
 //     workgroup barrier: pass p+1's LDS-DMA is issued before pass p is consumed, behind counted vmcnt waits.
-//   * the waves merge through LDS once.  With more than one live chunk, the hand-off to the workgroup that writes the output is
-//     (a) a TICKET (agent-scope fetch-add, one per workgroup) drawn right after the barrier that ends the pass loop, so that its
-//         round trip runs UNDER the in-LDS wave merge and the record stores instead of after them.  The add is issued by inline
-//         asm (hipcc would wait for a returning atomic on the spot); build.py audits the emitted ISA: nothing touches the
-//         destination register between the add and the claiming wait;
-//     (b) the chunk's record: per output element the chunk-normalised value o_c, per head the chunk's log-sum-exp, as 8-byte
-//         {value, tag} granules, stored by EVERY live chunk as soon as the wave merge has produced them: no drain, no flag;
-//     (c) the ticket is claimed and shared through LDS; every workgroup but the holder of the LAST ticket exits.  That one
-//         sweeps the other chunks' granules (their stores were issued about half a round trip after their tickets, all drawn
-//         before the last one: in practice every tag is set at the first sweep; the sweep repeats until they are, bounded, and a
-//         give-up writes NaN — it waits only on workgroups that have drawn a ticket, i.e. that are resident and have a few
-//         hundred instructions left, never on an undispatched one), merges all chunks IN CHUNK ORDER (bitwise repeatable
-//         whoever merges), writes the output, stores ZERO back over every granule of the pair and returns the ticket to zero:
-//         between launches the workspace holds no set tag and no drawn ticket (the state the caller's one-time zero fill
-//         established), whatever shapes and chunk counts the launches had.
-//     No combine launch (-4.7 us per layer); against the round-1 form (record stores -> vmcnt(0) -> barrier -> ticket -> barrier ->
-//     record loads: three dependent memory round trips after the wave merge) two remain, one of them under the wave merge.
+//   * the waves merge through LDS once; with more than one live chunk the workgroup publishes its (max, sum, O) record
+//     write-through (sc1 stores, vmcnt(0), barrier, ticket by a relaxed agent atomic) and the LAST ARRIVER of the
+//     (sequence, kv head) merges all records (sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
+//     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
+//     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
 template <int D, int NW>
 __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     // the operands on the way to the first DMA come first and flat: with -amdgpu-kernarg-preload-count they are in SGPRs when the
@@ -550,8 +529,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     const int32_t* __restrict__ p_context_lens, const int32_t* __restrict__ p_block_tables, const uint16_t* __restrict__ p_k_cache,
     const uint16_t* __restrict__ p_v_cache, const int p_kvh, const int p_block_size, const int p_max_blocks, const int p_chunks,
     const int p_bt_stride, const int p_bs_shift, const DecodeArgs a, const int G) {
-    // NW waves share a pass of SPLIT tokens: NW = 4 -> 64-token (D=64) / 32-token (D=128) tiles; NW = 8 (D=64 only) -> 32-token
-    // tiles, two waves per SIMD covering each other's LDS / MFMA latencies, same LDS footprint
+    // NW waves share a pass of SPLIT tokens: NW = 4 -> 64-token (D=64) / 32-token (D=128) tiles; NW = 8 -> 32-token (D=64) /
+    // 16-token (D=128) tiles, two waves per SIMD covering each other's LDS / MFMA latencies, same LDS footprint.  A 16-token tile
+    // contracts P V over 16 keys with v_mfma_f32_16x16x16_bf16 (one transposed V read per dim tile) instead of 32 with 16x16x32.
     constexpr int MW = NW;
     constexpr int SPLIT = MGeo<D>::SPLIT, WT = SPLIT / NW;
     constexpr int LPT = D / 8, TPI = 64 / LPT, NI = WT / TPI, ROWB = D * 2, NT = WT / 16, NHALF = WT / 32;
@@ -559,8 +539,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     constexpr int WAVES = NW;
     constexpr int WAVE_BYTES = 2 * IMG;                       // K + V image of one tile
     constexpr int WAVE_LDS = 2 * WAVE_BYTES;                  // two (K, V) image pairs per wave
-    static_assert(NHALF >= 1 && NI >= 1, "a wave tile is at least 32 tokens");
-    static_assert(16 * D * 4 <= IMG, "merge tile must fit in one K image");
+    constexpr bool HALF = WT == 16;                           // 16-token tiles: one 16-key PV step on the k = 16 MFMA
+    static_assert((NHALF >= 1 || HALF) && NI >= 1 && NT >= 1, "a wave tile is 16 tokens or a multiple of 32");
+    static_assert(16 * D * 4 <= WAVE_LDS, "merge tile must fit in the wave's images (all landed and read by then)");
     __shared__ __attribute__((aligned(16))) unsigned char lds[MW * WAVE_LDS + QI * 1024 + MW * 2 * 16 * 4 + 16];
     unsigned char* const lds_q = lds + MW * WAVE_LDS;
     float* const lds_ml = reinterpret_cast<float*>(lds_q + QI * 1024);              // [wave][max | sum][16 heads]
@@ -644,10 +625,6 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     void* const e_out = a.out;
     uint16_t* const e_out_packed = a.out_packed;
     const int e_out_f32 = a.out_f32, e_h = a.h;
-    const int live_chunks = min(NC, live_passes);
-    const int64_t pair = (int64_t)b * p_kvh + kh;
-    constexpr unsigned kTicketUnset = 0xffffffffu;
-    if (tid == 0) *lds_ticket = kTicketUnset;                 // (a barrier lies between this and every reader)
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
         // first K image, then q, then the first V image: everything the K DMA needs arrived with the wave (preloaded arguments,
         // the block id), while q's pointer is still behind a kernarg load; the first wait below (q and K landed) counts on q
@@ -708,6 +685,16 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                     for (int r = 0; r < 4; ++r)
                         if (16 * tt + 4 * lg + r >= n_live) sT[tt][r] = -INFINITY;
             }
+            // The max chain below reads the S^T accumulators through inline asm (max3), which hipcc does not pad: a VALU read of an
+            // MFMA result needs its wait states (8-pass XDL: 11) and the compiler only inserts them for instructions it can see.
+            // One statement that takes EVERY accumulator as an operand (so it follows every MFMA of the tile) carries the pad;
+            // without it a 16-token tile (one S^T accumulator, the max3 right behind its last MFMA) read a half-written
+            // accumulator now and then: a wrong running max, i.e. a correct softmax in another rounding (found as run-to-run
+            // differences of 1e-7 at D = 128 with 8 waves).
+            if constexpr (NT == 1) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sT[0]));
+            else if constexpr (NT == 2) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sT[0]), "+v"(sT[1]));
+            else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(sT[0]), "+v"(sT[1]), "+v"(sT[2]), "+v"(sT[3]));
+            static_assert(NT == 1 || NT == 2 || NT == 4, "tile shapes of the chunked kernel");
             float mx = sT[0][0];
 #pragma unroll
             for (int i = 1; i + 1 < 4 * NT; i += 2) mx = max3(mx, sT[i >> 2][i & 3], sT[(i + 1) >> 2][(i + 1) & 3]);
@@ -737,6 +724,31 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             if (pass == split) NVH_STAMP(5);
             // ---- O^T += V^T P^T, P as hi + lo bf16
             const int vq = lq >> 2, vp = lq & 3;              // lane 4q+p of its group addresses key row q, dims 4p..4p+3
+            if constexpr (HALF) {
+                // 16 keys: B = P^T straight from the one S^T accumulator (k-slot j -> key 4 lg + j), A = V^T by ONE transposed read
+                // per dim tile, both in the k order of v_mfma_f32_16x16x16_bf16
+                bf16x4 p_hi, p_lo;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float pv = sT[0][i];
+                    p_hi[i] = (__bf16)pv;
+                    p_lo[i] = (__bf16)(pv - (float)p_hi[i]);
+                }
+                const int R = 4 * lg + vq;
+                const uint32_t vrow = lds_offset(lds_v + R * ROWB + (vp & 1) * 8);
+                const int swz = chunk_swizzle_v<LPT>(R);
+                u32x2 vt[DT];
+#pragma unroll
+                for (int t = 0; t < DT; ++t) vt[t] = ds_read_tr16_b64_asm(vrow + ((2 * t + (vp >> 1)) ^ swz) * 16);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                typedef short s16x4 __attribute__((ext_vector_type(4)));
+                const s16x4 ph = __builtin_bit_cast(s16x4, p_hi), pl = __builtin_bit_cast(s16x4, p_lo);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vt[t]), ph, o[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) o[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, vt[t]), pl, o[t], 0, 0, 0);
+            }
 #pragma unroll
             for (int hh = 0; hh < NHALF; ++hh) {
                 bf16x8 p_hi, p_lo;
@@ -791,26 +803,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         }
     }
     __syncthreads();
-    // the workgroup's ticket, drawn NOW by the last wave's lane 0 (EXEC is narrowed inside the statement and restored): the add's
-    // round trip runs under the wave merge and the record stores below and is claimed after them
-    const bool drawer = wave == WAVES - 1 && live_chunks > 1;                     // wave-uniform
-    unsigned tk;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(tk));
-    if (drawer) {
-        unsigned long long exec_save;
-        asm volatile("s_nop 4\n\t"
-                     "s_mov_b64 %[sv], exec\n\t"
-                     "s_mov_b64 exec, 1\n\t"
-                     "s_nop 1\n\t"
-                     "global_atomic_add %[tk], %[off], %[one], %[base] sc0 ; NVH_TICKET_DRAW\n\t"
-                     "s_mov_b64 exec, %[sv]"
-                     : [tk] "+v"(tk), [sv] "=&s"(exec_save)
-                     : [off] "v"(0u), [one] "v"(1u), [base] "s"(e_counters + pair)
-                     : "memory");
-    }
 
     // ---- merge the live waves (those with a live tile in the workgroup's first pass), then the live chunks
     const int n_waves = min(WAVES, (ctx - split * SPLIT + WT - 1) / WT);
+    const int live_chunks = min(NC, live_passes);
     constexpr int EPT = 16 * D / (MW * 64);                   // elements per thread when G == 16
     float Mv[EPT], Lv[EPT], Ov[EPT];
 #pragma unroll
@@ -844,106 +840,76 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     }
     NVH_TSTAMP(1);
     if (live_chunks > 1) {
-        // this chunk's record: o_c = O / L (chunk-normalised) per output element and lse_c = max + log2(L) per head
+        const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
+        float* const recs = e_ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
+        float* const mine = recs + (int64_t)split * rec;
 #pragma unroll
         for (int e = 0; e < EPT; ++e) {
-            Ov[e] = Ov[e] / Lv[e];                             // L > 0: a live chunk holds at least one live token
-            Mv[e] = Mv[e] + fast_log2(Lv[e]);
-        }
-        constexpr unsigned tag = kGranuleTag;
-        const int rec = 16 + G * D;                           // granules per record: [16 heads: lse][G*D elements: o]
-        u64* const recs = reinterpret_cast<u64*>(e_ws_acc) + pair * NC * rec;
-        {
-            u64* const mine = recs + (int64_t)split * rec;
-#pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int idx = tid + e * WAVES * 64;
-                if (idx < G * D) {
-                    st_granule(mine + 16 + idx, Ov[e], tag);
-                    if (idx % D == 0) st_granule(mine + idx / D, Mv[e], tag);
+            const int idx = tid + e * WAVES * 64;
+            if (idx < G * D) {
+                st_sc1(mine + idx, Ov[e]);
+                if (idx % D == 0) {
+                    st_sc1(mine + G * D + idx / D, Mv[e]);
+                    st_sc1(mine + G * D + G + idx / D, Lv[e]);
                 }
             }
         }
         NVH_TSTAMP(2);
-        if (drawer) {                                          // claim: the add (and this wave's stores) have come back
-            asm volatile("s_waitcnt vmcnt(0) ; NVH_TICKET_CLAIM" : "+v"(tk)::"memory");
-            if (lane == 0) __hip_atomic_store(lds_ticket, tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        unsigned ticket;
-        while ((ticket = __hip_atomic_load(lds_ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == kTicketUnset) __builtin_amdgcn_s_sleep(1);
-        if (ticket != (unsigned)live_chunks - 1) return;       // workgroup-uniform: not the last one in
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         NVH_TSTAMP(3);
-        // holder of the last ticket.  One ATTEMPT = every granule it needs requested with no dependence between the requests (the
-        // compiler keeps them in flight together), merged speculatively in chunk order while a flag collects the tags; the
-        // attempt repeats only if some tag was not set yet.
-        constexpr unsigned kSpinLimit = 1u << 15;             // ~0.1 s: a corrupted workspace ends in NaN, not in a hang
-        bool ok = false;
-        float accv[EPT], Wv[EPT];
-        for (unsigned spins = 0; !ok; ++spins) {
-            ok = true;
+        if (tid == 0) {
+            unsigned* const ctr = e_counters + (int64_t)b * p_kvh + kh;
+            const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *lds_ticket = old;
+        }
+        __syncthreads();
+        NVH_TSTAMP(4);
+        if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
+        // records are requested CB at a time (every load of a batch in flight together); four chunks, the common shape of a
+        // full launch, are one batch of 12 loads per thread rather than an 8-wide batch with half of it repeated
+        auto merge_chunks = [&](auto cb_tag) {
+            constexpr int CB = decltype(cb_tag)::value;
 #pragma unroll
             for (int e = 0; e < EPT; ++e) {
                 const int idx = tid + e * WAVES * 64;
-                accv[e] = 0.f; Wv[e] = 1.f;
                 if (idx < G * D) {
                     const int g = idx / D;
-                    float Mx = -INFINITY, W = 0.f, acc = 0.f;
-                    constexpr int CB = 4;
+                    float M = -INFINITY, ov = 0.f, L = 0.f;
                     for (int c0 = 0; c0 < live_chunks; c0 += CB) {
-                        float ov[CB], lv[CB];
+                        float mv[CB], lv[CB], av[CB];
 #pragma unroll
                         for (int i = 0; i < CB; ++i) {
                             const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
-                            const u64* r = recs + (int64_t)c * rec;
-                            const u64 go = ld_granule(r + 16 + idx), gl = ld_granule(r + g);
-                            const bool own = c == split;       // own record from registers (its stores may still be in flight)
-                            ok &= own || ((unsigned)(go >> 32) == tag && (unsigned)(gl >> 32) == tag);
-                            ov[i] = own ? Ov[e] : __builtin_bit_cast(float, (unsigned)go);
-                            lv[i] = own ? Mv[e] : __builtin_bit_cast(float, (unsigned)gl);
+                            const float* r = recs + (int64_t)c * rec;
+                            mv[i] = ld_sc1(r + G * D + g);
+                            lv[i] = ld_sc1(r + G * D + G + g);
+                            av[i] = ld_sc1(r + idx);
                         }
-                        float Mc = Mx;
+                        float Mc = M;
 #pragma unroll
                         for (int i = 0; i < CB; ++i)
-                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, lv[i]);
-                        const float fo = fast_exp2(Mx - Mc);   // Mx = -inf on the first batch -> 0
-                        acc *= fo;
-                        W *= fo;
+                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, mv[i]);
+                        const float fo = fast_exp2(M - Mc);        // M = -inf on the first group -> 0
+                        ov *= fo;
+                        L *= fo;
 #pragma unroll
                         for (int i = 0; i < CB; ++i)
                             if (c0 + i < live_chunks) {
-                                const float w = fast_exp2(lv[i] - Mc);
-                                acc = fmaf(ov[i], w, acc);
-                                W += w;
+                                const float f = fast_exp2(mv[i] - Mc);
+                                ov = fmaf(av[i], f, ov);
+                                L = fmaf(lv[i], f, L);
                             }
-                        Mx = Mc;
+                        M = Mc;
                     }
-                    accv[e] = acc; Wv[e] = W;
+                    Lv[e] = L; Ov[e] = ov;
                 }
             }
-            if (!ok) {
-                if (spins >= kSpinLimit) break;
-                __builtin_amdgcn_s_sleep(4);
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            Ov[e] = ok ? accv[e] : __builtin_nanf("");
-            Lv[e] = Wv[e];
-        }
+        };
+        if (live_chunks <= 4) merge_chunks(std::integral_constant<int, 4>{});
+        else merge_chunks(std::integral_constant<int, 8>{});
         NVH_TSTAMP(5);
-        // the workspace as the next launch expects it: no tag set (own record included: same-address stores of one lane stay in
-        // order), no ticket drawn
-#pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + e * WAVES * 64;
-            if (idx < G * D)
-                for (int c = 0; c < live_chunks; ++c) {
-                    u64* r = recs + (int64_t)c * rec;
-                    __hip_atomic_store(r + 16 + idx, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (idx % D == 0) __hip_atomic_store(r + idx / D, (u64)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-        }
-        if (tid == 0) __hip_atomic_store(e_counters + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every ticket of the pair is in
     }
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
@@ -1035,17 +1001,15 @@ int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
 
 template <int D>
 int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
-    // D = 64: 8 waves (two per SIMD, 32-token tiles) measured 8.5 % faster than 4 waves of 64-token tiles (ctx 1536: 11.0 ->
-    // 10.05 us per call); a.waves = 4 (nvh_paged_decode_variant) selects the old shape.  D = 128 keeps 4 waves (its images are twice as large).
-    const int waves = a.waves == 4 ? 4 : 8;
+    // 8 waves (two per SIMD; 32-token tiles at D = 64, 16-token tiles at D = 128) by default: measured 8.5 % faster than 4 waves at
+    // D = 64 (ctx 1536: 11.0 -> 10.05 us per call); a.waves = 4 (nvh_paged_decode_variant) selects the one-wave-per-SIMD shape.
+    const int waves = a.waves == 4 ? 4 : (a.waves == 8 ? 8 : (D == 64 ? 8 : NVH_D128_WAVES));
     dim3 grid(a.kvh, a.batch, a.chunks);
     const int bs_shift = (a.block_size & (a.block_size - 1)) == 0 ? __builtin_ctz(a.block_size) : -1;
-    if constexpr (D == 64) {
-        if (waves == 8) {
-            hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
-                               a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
-            return check_launch("paged_decode_chunked");
-        }
+    if (waves == 8) {
+        hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
+                           a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
+        return check_launch("paged_decode_chunked");
     }
     hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 4>), grid, dim3(4 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache, a.kvh,
                        a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
@@ -1078,12 +1042,10 @@ static int device_cus() {
 }
 
 // workgroups per (sequence, kv head): one wave of workgroups over the chip, at most one per pass; `forced` > 0 (the
-// variant entry point, tests and A/B runs) lowers the choice
+// variant entry point, tests and A/B runs) overrides the choice
 int decode_chunks(int batch, int kvh, int num_splits, int forced) {
-    // never more workgroups than CUs (one workgroup per CU by its LDS footprint): a second round of workgroups costs far more than
-    // the pass imbalance it removes (round 1: 12.5 vs 9.7 us), and the holder of a pair's last ticket then never waits long
-    const int most = device_cus() / (batch * kvh);
-    int c = forced > 0 && forced < most ? forced : most;
+    const int cus = device_cus();
+    int c = forced > 0 ? forced : (cus + batch * kvh / 2) / (batch * kvh);
     if (c < 1) c = 1;
     return c > num_splits ? num_splits : c;
 }

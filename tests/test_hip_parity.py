@@ -80,7 +80,8 @@ def test_store_kvcache_empty_and_all_skipped(ops):
 # and north_star's literal VALU + wavefront-reduction form + combine.  {} = the plain nvh_paged_decode call.
 VARIANTS = {
     "default": {},
-    "chunked_w4": dict(variant="chunked", waves=4),
+    "chunked_w4": dict(variant="chunked", waves=4),          # one wave per SIMD: 64-token (D=64) / 32-token (D=128) tiles
+    "chunked_w8": dict(variant="chunked", waves=8),          # two per SIMD: 32-token / 16-token tiles (the k = 16 MFMA at D=128)
     "chunked_c1": dict(variant="chunked", chunks=1),
     "chunked_c3": dict(variant="chunked", chunks=3),
     "chunked_c16_w4": dict(variant="chunked", chunks=16, waves=4),

@@ -7,10 +7,13 @@ rc=$?
 tail -12 gpurun_out/r2b/pytest.log
 [ $rc -ne 0 ] && exit $rc
 rm -f gpurun_out/r2b/micro.log
-for ctx in 1025 1536 2048; do
-  timeout -k 10 120 python tools/microbench.py decode --batch 32 --ctx $ctx --graph --width 16 >> gpurun_out/r2b/micro.log 2>&1 || exit 1
+mb() { timeout -k 10 120 python tools/microbench.py decode --graph "$@" >> gpurun_out/r2b/micro.log 2>&1 || exit 1; }
+for ctx in 1025 1536 2048; do mb --batch 32 --ctx $ctx --width 16; done
+mb --batch 64 --ctx 3072 --width 16
+for w in 4 8; do
+  echo "# waves $w" >> gpurun_out/r2b/micro.log
+  mb --batch 32 --ctx 1536 --heads 7 --kv-heads 1 --head-dim 128 --waves $w
+  mb --batch 32 --ctx 1536 --heads 16 --kv-heads 8 --head-dim 128 --waves $w
+  mb --batch 32 --ctx 1536 --heads 28 --kv-heads 4 --head-dim 128 --waves $w
 done
-timeout -k 10 120 python tools/microbench.py decode --batch 32 --ctx 1536 --graph --heads 7 --kv-heads 1 --head-dim 128 >> gpurun_out/r2b/micro.log 2>&1 || exit 1
-timeout -k 10 120 python tools/microbench.py decode --batch 64 --ctx 3072 --graph --width 16 >> gpurun_out/r2b/micro.log 2>&1 || exit 1
-timeout -k 10 120 python tools/microbench.py decode --batch 32 --ctx 1536 --graph --heads 16 --kv-heads 8 --head-dim 128 >> gpurun_out/r2b/micro.log 2>&1 || exit 1
-grep us_per_call gpurun_out/r2b/micro.log
+grep "us_per_call\|# waves" gpurun_out/r2b/micro.log | cut -c1-200

@@ -35,9 +35,7 @@ def main():
     q = torch.randn(b, h, d, device="cuda", dtype=torch.bfloat16)
     out = torch.empty_like(q)
     nsplit = (nblk * bs + 255) // 256
-    lib.nvh_paged_decode_workspace.restype = ctypes.c_size_t
-    lib.nvh_paged_decode_workspace.argtypes = [ctypes.c_int] * 5
-    ws = torch.zeros(lib.nvh_paged_decode_workspace(b, h, d, nblk, bs), dtype=torch.uint8, device="cuda")   # ticket header + chunk records
+    ws = torch.zeros(65536 + b * h * nsplit * (d + 2) * 4, dtype=torch.uint8, device="cuda")   # ticket header + partial records
     waves = 8 if d == 64 else 4                                       # waves per workgroup of the chunked kernel
     stamps = torch.zeros(b * kvh * nsplit * waves * 8, dtype=torch.int64, device="cuda")
     lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
@@ -55,25 +53,21 @@ def main():
     st = stamps.cpu().numpy().reshape(-1, waves, 8).astype(np.float64) * 0.01     # us
     st = st[st[:, 0, 1] > 0]                                                   # live workgroups only
     t0 = st[:, :, 0].min()
-    names = ["start", "waves merged in LDS", "granule stores issued (not last)", "sweep starts (last ticket)", "-", "records read + merged (last ticket)",
+    names = ["start", "waves merged in LDS", "record stores issued", "stores acknowledged + barrier", "ticket returned + barrier", "records read + merged (last arriver)",
              "all passes done", "written (last arriver)"] if args.tail else ["start", "scalars+branch", "first loads issued", "first K landed", "first QK+softmax done", "first V landed", "all passes done",
              "merged + written (last arriver)"]
     print(f"live workgroups {st.shape[0]}, kernel span {st[:, :, 7].max() - t0:.2f} us (first wave start -> last wave end)")
-    order = [0, 6, 1, 2, 3, 5, 7] if args.tail else list(range(8))
+    order = [0, 6, 1, 2, 3, 4, 5, 7] if args.tail else list(range(8))
     for pos, k in enumerate(order):
         n = names[k]
         ok = st[:, :, k] > 0
         v = (st[:, :, k] - t0)[ok]
-        if v.size == 0:
-            print(f"  {k} {n:<32} (no stamps)")
-            continue
         line = f"  {k} {n:<32} abs: min {v.min():6.2f} med {np.median(v):6.2f} p90 {np.percentile(v, 90):6.2f} max {v.max():6.2f}"
         if pos:
             kp = order[pos - 1]
             both = ok & (st[:, :, kp] > 0)
             d = (st[:, :, k] - st[:, :, kp])[both]
-            if d.size:
-                line += f"   delta vs prev: med {np.median(d):5.2f} max {d.max():5.2f}"
+            line += f"   delta vs prev: med {np.median(d):5.2f} max {d.max():5.2f}"
         print(line)
     if args.tail:                                                              # per-workgroup critical path (the barrier hides wave skew)
         done = st[:, :, 6].max(axis=1); first_done = np.where(st[:, :, 6] > 0, st[:, :, 6], np.inf).min(axis=1)
@@ -81,7 +75,7 @@ def main():
         print(f"  per workgroup: wave skew at the end of the passes med {np.median(done - first_done):.2f} max {(done - first_done).max():.2f}; "
               f"last wave done -> merged med {np.median(merged - done):.2f} max {(merged - done).max():.2f}")
         last = st[:, 0, 5] > 0
-        seq = [6, 1, 3, 5, 7]
+        seq = [6, 1, 2, 3, 4, 5, 7]
         tl = [np.median(st[last][:, :, k].max(axis=1) - t0) for k in seq]
         print("  last arrivers (median abs, max over waves):", " ".join(f"{names[k].split(' (')[0]}={v:.2f}" for k, v in zip(seq, tl)))
         starts = st[:, :, 0].min(axis=1) - t0
