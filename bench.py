@@ -13,12 +13,18 @@ body around it, replayed from a HIP graph with device-resident metadata.  Prefil
 region (it is reported separately, and the bench_my-style figure that includes it is in `bench_my_tok_s`).
 The K timed steps start at context 1025 as bench_my's decode phase does (K = 1024 covers 1025 -> 2048).
 
-Output: ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Output: ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      the decode attention op (nvh_paged_decode: one chunked split-KV launch, combine included) at the mean context of the
                 timed window, timed live with HIP events on the launching stream over a graph of per-layer calls
-                on distinct caches; achieved = algorithmic bytes / average time per call.
-  cpu_baseline  the CPU port of the reference's sdpa.math decode (oracle/sdpa_math_cpu.py, "port"), timed on
-                this host on a bounded sample of the same attention call; rank 0, N = 1 only.
+                on distinct caches; achieved = algorithmic bytes / average time per call; traffic = HBM bytes per call from the
+                committed rocprofv3 PMC passes (profiles/r02_pmc_decode_traffic.json), taken at the profiled context nearest to
+                the measured one and scaled by the ratio of algorithmic bytes (the line says which context it came from).
+  prefill       the varlen prefill attention op (nvh_prefill_varlen) timed the same way at BASELINE config 5 (one scheduler
+                batch: 128 sequences x 128 tokens) and at S = 1024 (16 sequences: one prefill batch of config 2), with flops,
+                bytes, bound = the slower of HBM and MFMA at their peaks, and the fraction of that bound achieved.
+  cpu_baseline  the CPU port of the reference's sdpa.math attention (oracle/sdpa_math_cpu.py, "port"), timed on this host on
+                bounded samples: the bs=32 decode call of this workload, and (`config1`) BASELINE config 1's shape (bs=1,
+                in=out=512: one 512-token prefill call and decode calls over contexts 513..1024); rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -35,6 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "nano-vllm-learn_amd"))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 
 
 def decode_attn_bytes(ctxs, h, kvh, d, bs=256, with_store=True):
@@ -96,46 +103,128 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     return us, nbytes, (h, kvh, d)
 
 
-def pmc_traffic(cfg, tp, batch, ctx):
-    """HBM bytes per attention call from the committed rocprofv3 PMC passes (profiles/r01_pmc_decode_traffic.json:
-    FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE), attached only when the profiled workload is this one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_decode_traffic.json")
-    try:
-        p = json.load(open(path))
-    except OSError:
-        return None
-    w = p["workload"]
-    same = (tp == 1 and w["batch"] == batch and w["ctx"] == ctx and w["heads"] == cfg.num_attention_heads and
-            w["kv_heads"] == cfg.num_key_value_heads and w["head_dim"] == cfg.head_dim)
-    return p["hbm_bytes_per_attention_call"] if same else None
+def pmc_traffic(cfg, tp, batch, ctx, attn_bytes):
+    """HBM bytes per attention call from the committed rocprofv3 PMC passes (profiles/r02_pmc_decode_traffic.json: one
+    --pmc FETCH_SIZE and one --pmc WRITE_SIZE pass of tools/microbench.py per profiled context; FETCH_SIZE doubled per the
+    gfx950 correction, + WRITE_SIZE).  The record of the profiled context nearest to `ctx` is scaled by the ratio of
+    algorithmic bytes (measured / algorithmic is 1.04-1.06 at every profiled context: the kernel reads each K/V byte once).
+    Returns (bytes, note) or (None, reason)."""
+    for name in ("r02_pmc_decode_traffic.json", "r01_pmc_decode_traffic.json"):
+        try:
+            p = json.load(open(os.path.join(ROOT, "profiles", name)))
+            break
+        except OSError:
+            p = None
+    if p is None:
+        return None, "no committed PMC record"
+    recs = p["records"] if "records" in p else [p]
+    same = [r for r in recs if tp == 1 and r["workload"]["batch"] == batch and r["workload"]["heads"] == cfg.num_attention_heads and
+            r["workload"]["kv_heads"] == cfg.num_key_value_heads and r["workload"]["head_dim"] == cfg.head_dim]
+    if not same:
+        return None, "no PMC record for this shape"
+    r = min(same, key=lambda r: abs(r["workload"]["ctx"] - ctx))
+    ratio = r["hbm_bytes_per_attention_call"] / r["algorithmic_bytes_per_attention_call"]
+    note = (f"rocprofv3 PMC (FETCH_SIZE x2 + WRITE_SIZE) at ctx {r['workload']['ctx']}: {r['hbm_bytes_per_attention_call']} B per call = "
+            f"{ratio:.3f} x algorithmic" + ("" if r["workload"]["ctx"] == ctx else f"; scaled to ctx {ctx} by algorithmic bytes"))
+    return int(round(ratio * attn_bytes)), note
 
 
-def cpu_baseline_leg(cfg, batch, ctx, budget_s=12.0):
-    """Time the CPU port of the reference's sdpa.math decode call (one layer, bf16 like the reference) on the host."""
-    from oracle.sdpa_math_cpu import flash_attn_with_kvcache_cpu
+@torch.inference_mode()
+def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6):
+    """Time nvh_prefill_varlen alone on `batch` sequences of `seq` tokens (q / k / v strided views of a fused projection
+    output, as the model hands them over), cycling over distinct inputs (more than the 256 MiB Infinity Cache in total) between
+    two HIP events on the launching stream."""
+    from nanovllm_hip import ops
+    from nanovllm_hip.models.qwen import tp_partition
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    _, h, _, kvh = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
+    d = cfg.head_dim
+    t = batch * seq
+    dev = torch.device("cuda", torch.cuda.current_device())
+    qkvs = [torch.randn(t, (h + 2 * kvh) * d, device=dev, dtype=torch.bfloat16) for _ in range(buffers)]
+    cu = torch.arange(0, t + 1, seq, dtype=torch.int32, device=dev)
+
+    def call(x):
+        q, k, v = x[:, :h * d].view(t, h, d), x[:, h * d:(h + kvh) * d].view(t, kvh, d), x[:, (h + kvh) * d:].view(t, kvh, d)
+        return ops.flash_attn_varlen_func(q, k, v, seq, cu, seq, cu)
+
+    for x in qkvs[:2]:
+        call(x)
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        for x in qkvs:
+            call(x)
+    end.record()
+    torch.cuda.synchronize()
+    us = start.elapsed_time(end) * 1e3 / (iters * buffers)
+    flops = batch * 4 * d * h * seq * (seq + 1) / 2                    # QK^T + PV over the causal triangle incl. the diagonal (SURVEY 8d)
+    nbytes = t * (2 * h + 2 * kvh) * d * 2                              # q in, o out, k and v in
+    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e3), flops / (MFMA_PEAK_TFLOPS * 1e6)     # us at the two peaks
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    return {"workload": f"{batch} sequences x {seq} tokens, H/KVH/D = {h}/{kvh}/{d}", "us_per_launch": round(us, 2), "flops_per_launch": int(flops),
+            "bytes_per_launch": int(nbytes), "achieved_TFLOPs": round(flops / us / 1e6, 1), "achieved_GBps": round(nbytes / us / 1e3, 1),
+            "bound": bound, "us_at_bound": round(max(t_hbm, t_mfma), 2), "frac": round(max(t_hbm, t_mfma) / us, 4),
+            "frac_of_mfma_peak": round(flops / us / 1e6 / MFMA_PEAK_TFLOPS, 4), "frac_of_hbm_peak": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)}
+
+
+def _cpu_decode_case(cfg, batch, ctx, seed=0):
     h, kvh, d, bs = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.kvcache_block_size
     nblk = (ctx + bs - 1) // bs
     nb = batch * nblk + 1
-    gen = torch.Generator().manual_seed(0)
+    gen = torch.Generator().manual_seed(seed)
     kc = torch.randn(nb, bs, kvh, d, generator=gen).bfloat16()
     vc = torch.randn(nb, bs, kvh, d, generator=gen).bfloat16()
     q = torch.randn(batch, 1, h, d, generator=gen).bfloat16()
     bt = torch.randperm(nb - 1, generator=gen)[: batch * nblk].view(batch, nblk).int()
     cl = torch.full((batch,), ctx, dtype=torch.int32)
-    flash_attn_with_kvcache_cpu(q, kc, vc, cl, bt)                      # warm-up
+    return q, kc, vc, cl, bt
+
+
+def _time_cpu(fn, budget_s, max_reps):
+    fn()                                                                # warm-up
     reps, t0 = 0, time.perf_counter()
     while True:
-        flash_attn_with_kvcache_cpu(q, kc, vc, cl, bt)
+        fn()
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 96:            # ~10-15 s of host work: four decode steps' worth of layer calls at most
-            break
-    per_call = el / reps
+        if el >= budget_s or reps >= max_reps:
+            return el / reps, reps, el
+
+
+def cpu_baseline_leg(cfg, batch, ctx, budget_s=10.0):
+    """Time the CPU port of the reference's sdpa.math attention (bf16 like the reference) on the host: the decode call of this
+    workload (one layer, bs = `batch`), and BASELINE config 1's shape (bs = 1, in = out = 512) as a second bounded sample."""
+    from oracle.sdpa_math_cpu import flash_attn_varlen_func_cpu, flash_attn_with_kvcache_cpu
+    h, kvh, d = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     layers = cfg.num_hidden_layers
+    case = _cpu_decode_case(cfg, batch, ctx)
+    per_call, reps, el = _time_cpu(lambda: flash_attn_with_kvcache_cpu(*case), budget_s, 96)   # ~10 s: four decode steps' worth of layer calls at most
+    # ---- config 1 (bs=1, in=out=512, --attn-backend sdpa.math on CPU): attention work of one generate() = one 512-token prefill call
+    # and 512 decode calls at contexts 513..1024, per layer; sampled at three contexts (~2 s each), the rest interpolated linearly
+    gen = torch.Generator().manual_seed(1)
+    n_in = n_out = 512
+    qkv = torch.randn(n_in, (h + 2 * kvh) * d, generator=gen).bfloat16()
+    qp, kp, vp = qkv[:, :h * d].view(n_in, h, d), qkv[:, h * d:(h + kvh) * d].view(n_in, kvh, d), qkv[:, (h + kvh) * d:].view(n_in, kvh, d)
+    cu = torch.tensor([0, n_in], dtype=torch.int32)
+    pre_s, pre_reps, _ = _time_cpu(lambda: flash_attn_varlen_func_cpu(qp, kp, vp, cu, cu), 1.5, 40)
+    dec = {}
+    for c in (n_in + 1, n_in + n_out // 2, n_in + n_out):
+        one = _cpu_decode_case(cfg, 1, c, seed=c)
+        dec[c], _, _ = _time_cpu(lambda: flash_attn_with_kvcache_cpu(*one), 1.5, 400)
+    cs = sorted(dec)
+    mean_dec = (dec[cs[0]] + 2 * dec[cs[1]] + dec[cs[2]]) / 4            # trapezoid over the 512 contexts
+    total = layers * (pre_s + n_out * mean_dec)
     return {"value": round(batch / (per_call * layers), 2), "unit": "tok/s (attention path only: one decode step = %d layer calls)" % layers,
             "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} calls of the sdpa.math decode attention (B={batch}, ctx={ctx}, H/KVH/D={h}/{kvh}/{d}, bf16) in {el:.1f} s; "
-                      f"{per_call * 1e3:.1f} ms per layer call; host cpu_count={os.cpu_count()}"}
+                      f"{per_call * 1e3:.1f} ms per layer call; host cpu_count={os.cpu_count()}",
+            "config1": {"value": round(n_out / total, 2), "unit": "tok/s (attention path only, bs=1 in=512 out=512, %d layers)" % layers,
+                        "workload": "BASELINE config 1 shape: Qwen2-0.5B bs=1 in=out=512, sdpa.math attention on CPU",
+                        "sample": f"prefill call (512 tokens) {pre_s * 1e3:.2f} ms x {pre_reps} reps; decode calls at ctx "
+                                  + ", ".join(f"{c}: {dec[c] * 1e3:.3f} ms" for c in cs) + "; other contexts interpolated",
+                        "cores": torch.get_num_threads(), "kind": "port"}}
 
 
 def main():
@@ -148,6 +237,7 @@ def main():
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no HIP graph (debug)")
+    ap.add_argument("--prefill-leg", action="store_true", help="time the prefill attention op for models other than the headline one too")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -212,6 +302,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    graph_mode = sess.graph is not None
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,6 +314,15 @@ def main():
     tp = world
     attn_us, attn_bytes, shape_rank = attention_leg(cfg, tp, args.batch, mean_ctx, cfg.num_hidden_layers)
     achieved = attn_bytes / attn_us / 1e3                              # GB/s
+
+    traffic, traffic_note = pmc_traffic(cfg, tp, args.batch, mean_ctx, attn_bytes)
+    prefill = None
+    if args.model == "Qwen2-0.5B" or args.prefill_leg:
+        del sess
+        torch.cuda.empty_cache()
+        prefill = {"config5_half": prefill_leg(cfg, tp, 128, 128), "s1024": prefill_leg(cfg, tp, 16, 1024, buffers=8, iters=4)}
+    from nanovllm_hip.models.qwen import tp_partition
+    shapes = [list(tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)) for r in range(tp)]
 
     result = None
     if rank == 0:
@@ -236,16 +336,19 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random prompts randint(0,10000) seed 0; random-init weights N(0,0.02) seed 0)" + (" REHEARSAL over gloo on one GPU: not a measurement" if rehearse else ""),
             "config": {"workload": f"{args.model} bs={args.batch} in={args.input_len} decode steps={args.steps} --attn-backend hip, "
-                                   f"TP={tp}, {'HIP-graph replay' if sess.graph is not None else 'eager steps (graph capture unavailable)'}, device-resident metadata",
-                       "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}"},
+                                   f"TP={tp}, {'HIP-graph replay' if graph_mode else 'eager steps (graph capture unavailable)'}, device-resident metadata",
+                       "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}",
+                       "collective": (f"{dist.get_backend()} world_size {world} (torch.distributed; nccl = RCCL over xGMI)" if world > 1 else "none (single GPU)"),
+                       "heads_per_rank_q0_qn_kv0_kvn": shapes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": pmc_traffic(cfg, tp, args.batch, mean_ctx),
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "kernel": "one decode attention call (nvh_paged_decode) = one launch of paged_decode_chunked_kernel (split-KV passes + last-arriver combine)",
                          "bytes_per_launch": attn_bytes, "us_per_launch": round(attn_us, 2), "context": mean_ctx,
                          "shape_per_rank": list(shape_rank)},
             "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),
                                      "frac": round(step_bytes / 8e6 / step_us, 4),
                                      "attention_share_of_step": round(cfg.num_hidden_layers * attn_us / step_us, 3)},
+            "prefill": prefill,
             "prefill_s": round(prefill_s, 4),
             "bench_my_tok_s": round(args.batch * (args.steps + 1) / (prefill_s + elapsed), 1),
             "attention_only_tok_s": round(args.batch / (attn_us * 1e-6 * cfg.num_hidden_layers), 1),

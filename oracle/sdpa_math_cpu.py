@@ -37,3 +37,23 @@ def flash_attn_with_kvcache_cpu(q, k_cache, v_cache, cache_seqlens, block_table)
     probs = torch.softmax(scores, dim=-1)
     probs = torch.nan_to_num(probs, nan=0.0)                                      # all-masked rows (ctx == 0) -> zeros
     return (probs @ vh).transpose(1, 2)                                           # [B, 1, H, D]
+
+
+def flash_attn_varlen_func_cpu(q, k, v, cu_seqlens_q, cu_seqlens_k):
+    """CPU port of the reference's sdpa.math prefill (attention_sdpa.py:65-119): a Python loop over the sequences of the packed
+    batch (:83-92), each one a causal softmax(QK^T/sqrt(D))V with GQA sharing (the SDPA call :101-110, math backend, written
+    out as its definition: scores materialised [H, Sq, Sk], top-left causal mask as `is_causal=True` builds it).
+    q [Tq, H, D]; k, v [Tk, KVH, D]; cu_seqlens int32 [B+1].  tests/test_oracle_golden.py pins it to the reference's outputs."""
+    h, d = q.shape[1], q.shape[2]
+    g = h // k.shape[1]
+    outs = []
+    for i in range(cu_seqlens_q.numel() - 1):
+        qi = q[cu_seqlens_q[i]:cu_seqlens_q[i + 1]].transpose(0, 1)               # [H, Sq, D]
+        ki = k[cu_seqlens_k[i]:cu_seqlens_k[i + 1]].transpose(0, 1).repeat_interleave(g, dim=0)
+        vi = v[cu_seqlens_k[i]:cu_seqlens_k[i + 1]].transpose(0, 1).repeat_interleave(g, dim=0)
+        sq, sk = qi.shape[1], ki.shape[1]
+        scores = (qi @ ki.transpose(-1, -2)) / math.sqrt(d)
+        mask = torch.ones(sq, sk, dtype=torch.bool).tril()                        # is_causal: top-left aligned
+        scores = scores.masked_fill(~mask, float("-inf"))
+        outs.append((torch.softmax(scores, dim=-1) @ vi).transpose(0, 1))         # [Sq, H, D]
+    return torch.cat(outs, dim=0)

@@ -122,6 +122,18 @@ def test_sdpa_math_cpu_port_matches_reference(golden, name):
     assert np.abs(out[:, 0].numpy() - g["expected"]).max() <= TOL
 
 
+@pytest.mark.parametrize("name", PREFILL)
+def test_sdpa_math_cpu_prefill_port_matches_reference(golden, name):
+    """The torch port of the reference's prefill timed in `cpu_baseline` (config 1 sample) equals the reference's output."""
+    import torch
+    from oracle.sdpa_math_cpu import flash_attn_varlen_func_cpu
+    g = golden(name)
+    cu = torch.from_numpy(g["cu_seqlens"])
+    out = flash_attn_varlen_func_cpu(torch.from_numpy(O.bf16_bits_to_f32(g["q"])), torch.from_numpy(O.bf16_bits_to_f32(g["k"])),
+                                     torch.from_numpy(O.bf16_bits_to_f32(g["v"])), cu, cu)
+    assert np.abs(out.numpy() - g["expected"]).max() <= TOL
+
+
 @pytest.mark.parametrize("name", ["rope_d64.npz", "rope_d128.npz"])
 def test_rope_restatement_matches_reference(golden, name):
     """oracle.rope_neox / rope_cos_sin against the reference's apply_rotary_emb + cos_sin_cache (bit-exact bf16)."""
