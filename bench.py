@@ -338,7 +338,9 @@ def main():
             "config": {"workload": f"{args.model} bs={args.batch} in={args.input_len} decode steps={args.steps} --attn-backend hip, "
                                    f"TP={tp}, {'HIP-graph replay' if graph_mode else 'eager steps (graph capture unavailable)'}, device-resident metadata",
                        "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}",
-                       "collective": (f"{dist.get_backend()} world_size {world} (torch.distributed; nccl = RCCL over xGMI)" if world > 1 else "none (single GPU)"),
+                       "collective": ((f"{dist.get_backend()} world_size {world} (torch.distributed; nccl = RCCL over xGMI); decode all-reduces: "
+                                       + ("one-shot over IPC-mapped peer buffers with the residual add fused in (nvh_allreduce_oneshot), inside the HIP graph"
+                                          if engine.runner.comm is not None else "RCCL ring through torch.distributed")) if world > 1 else "none (single GPU)"),
                        "heads_per_rank_q0_qn_kv0_kvn": shapes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,

@@ -313,6 +313,42 @@ int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_
 /* offset (in elements) of activation element (row, col) of an [m, cols] matrix in fragment order */
 int64_t nvh_pack_index(int row, int col, int cols);
 
+/*
+ * "Next" row: the step immediately AFTER attention under tensor parallelism — the all-reduce of the
+ * row-parallel projections' partial sums (RowParallelLinear.forward, nanovllm/layers/linear.py:185-190: dist.all_reduce over
+ * NCCL) with the residual add that follows it (add_rms_forward, nanovllm/layers/layernorm.py:35-36) fused in.  One-shot over
+ * xGMI instead of RCCL's ring: every rank maps every peer's staging buffer and flag table through hipIpc handles, signals with
+ * one remote store per peer, reads the p-1 peers' partials over p-1 distinct links at once and sums in rank order in fp32 (all
+ * ranks produce the same bits).  Decode-sized messages ([<= 64, hidden] bf16); capture-safe; no trailing barrier (staging is
+ * double-buffered by a device-resident epoch).  A dead peer ends in NaN rows and a failure mark, not a hang.
+ *
+ * Set-up (host-synchronous, once, NOT capturable), per rank:
+ *   nvh_comm_alloc(&stage, nvh_allreduce_stage_bytes(max_rows, hidden));   nvh_comm_alloc(&flags, nvh_allreduce_flag_bytes(world));
+ *   nvh_comm_alloc(&state, 64);                                            (zero-filled fine-grained device memory)
+ *   nvh_comm_ipc_export(stage / flags, handle[NVH_COMM_IPC_HANDLE_BYTES]) -> exchange the handles by any host channel ->
+ *   nvh_comm_ipc_open(peer handle, &peer_ptr) for every peer; upload the two [world] pointer tables (own pointers at [rank])
+ *   to device memory.  `state` stays local.
+ * Call (every rank, same order of calls, same rows / hidden):
+ *   x              [rows, hidden] bf16 partial sums of this rank (row stride x_row_stride elements)
+ *   epilogue       NVH_AR_EPI_NONE: out[rows, hidden] = bf16(sum over ranks);  out may alias x
+ *                  NVH_AR_EPI_RESIDUAL_ADD: out is the residual stream: out = bf16(out + bf16(sum)); packed (nullable): the
+ *                  updated rows again in fragment order (nvh_pack_index) for the next nvh_linear_small_m_ex with x_packed
+ *   stage_bytes    size of EACH rank's staging buffer (>= nvh_allreduce_stage_bytes(rows, hidden))
+ *   state          uint32[16], local: [0] calls completed, [2] != 0 after a peer timed out (the epoch that failed)
+ */
+#define NVH_COMM_IPC_HANDLE_BYTES 64
+enum { NVH_AR_EPI_NONE = 0, NVH_AR_EPI_RESIDUAL_ADD = 1 };
+int nvh_comm_alloc(void** ptr, size_t bytes);
+int nvh_comm_free(void* ptr);
+int nvh_comm_ipc_export(void* ptr, void* handle_out);
+int nvh_comm_ipc_open(const void* handle, void** ptr);
+int nvh_comm_ipc_close(void* ptr);
+size_t nvh_allreduce_stage_bytes(int max_rows, int hidden);
+size_t nvh_allreduce_flag_bytes(int world);
+int nvh_allreduce_oneshot(void* out, const void* x, void* packed, void* const* stage_ptrs, void* const* flag_ptrs, void* state,
+                          int world, int rank, int rows, int hidden, int64_t x_row_stride, int64_t out_row_stride,
+                          size_t stage_bytes, int epilogue, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

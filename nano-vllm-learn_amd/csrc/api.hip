@@ -3,6 +3,7 @@
 // Nothing here allocates, synchronises or reads device memory: every entry point is capture-safe.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/nvh_attn.h"
 #include "common.h"
@@ -503,5 +504,68 @@ int nvh_greedy_advance_candidates_embed(const float* candidate_val, const int32_
                                           embed_weight, vocab, hidden, hidden_out, hidden_row_stride, hidden_packed, stream);
 }
 int64_t nvh_pack_index(int row, int col, int cols) { return pack_index(row, col, cols); }
+
+// ---- one-shot all-reduce over IPC-mapped peer buffers: set-up helpers (host-synchronous, not capturable) and the launch
+static int hip_rc(const char* what, hipError_t e) {
+    if (e == hipSuccess) return 0;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    (void)hipGetLastError();
+    return (int)e;
+}
+
+int nvh_comm_alloc(void** ptr, size_t bytes) {
+    if (!ptr || bytes == 0) { set_error("comm_alloc: null pointer or zero size"); return NVH_E_NULL; }
+    // fine-grained device memory: peers read and write it while kernels of this device run; coherence comes from the
+    // system-scope fences and atomics of the all-reduce kernel
+    int rc = hip_rc("comm_alloc: hipExtMallocWithFlags", hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained));
+    if (rc) return rc;
+    rc = hip_rc("comm_alloc: hipMemset", hipMemset(*ptr, 0, bytes));
+    if (!rc) rc = hip_rc("comm_alloc: hipDeviceSynchronize", hipDeviceSynchronize());
+    return rc;
+}
+int nvh_comm_free(void* ptr) { return ptr ? hip_rc("comm_free", hipFree(ptr)) : 0; }
+int nvh_comm_ipc_export(void* ptr, void* handle_out) {
+    if (!ptr || !handle_out) { set_error("comm_ipc_export: null pointer"); return NVH_E_NULL; }
+    static_assert(sizeof(hipIpcMemHandle_t) == NVH_COMM_IPC_HANDLE_BYTES, "handle size of the C ABI");
+    return hip_rc("comm_ipc_export: hipIpcGetMemHandle", hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle_out), ptr));
+}
+int nvh_comm_ipc_open(const void* handle, void** ptr) {
+    if (!handle || !ptr) { set_error("comm_ipc_open: null pointer"); return NVH_E_NULL; }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    return hip_rc("comm_ipc_open: hipIpcOpenMemHandle", hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+}
+int nvh_comm_ipc_close(void* ptr) { return ptr ? hip_rc("comm_ipc_close", hipIpcCloseMemHandle(ptr)) : 0; }
+
+size_t nvh_allreduce_stage_bytes(int max_rows, int hidden) {
+    if (max_rows <= 0 || hidden <= 0 || hidden % 8) return 0;
+    return 2 * (((size_t)max_rows * hidden * 2 + 255) & ~(size_t)255);           // two slots (epoch parity)
+}
+size_t nvh_allreduce_flag_bytes(int world) { return world > 0 ? (size_t)world * AR_MAX_BLOCKS * sizeof(uint32_t) : 0; }
+
+int nvh_allreduce_oneshot(void* out, const void* x, void* packed, void* const* stage_ptrs, void* const* flag_ptrs, void* state,
+                          int world, int rank, int rows, int hidden, int64_t x_row_stride, int64_t out_row_stride,
+                          size_t stage_bytes, int epilogue, int dtype, void* stream) {
+    if (rows == 0) return 0;
+    if (dtype != NVH_BF16) { set_error("allreduce_oneshot: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
+    if (!out || !x || !stage_ptrs || !flag_ptrs || !state) { set_error("allreduce_oneshot: null pointer"); return NVH_E_NULL; }
+    if (world < 2 || world > 64 || rank < 0 || rank >= world || rows < 0 || hidden <= 0 || hidden % 8) {
+        set_error("allreduce_oneshot: world %d (2..64) rank %d rows %d hidden %d (%%8)", world, rank, rows, hidden);
+        return NVH_E_SHAPE;
+    }
+    if (epilogue != NVH_AR_EPI_NONE && epilogue != NVH_AR_EPI_RESIDUAL_ADD) { set_error("allreduce_oneshot: unknown epilogue %d", epilogue); return NVH_E_SHAPE; }
+    if (packed && (epilogue != NVH_AR_EPI_RESIDUAL_ADD || hidden % 32)) { set_error("allreduce_oneshot: packed needs the residual-add epilogue and hidden %% 32 == 0"); return NVH_E_SHAPE; }
+    if (x_row_stride % 8 || out_row_stride % 8 || x_row_stride < hidden || out_row_stride < hidden) { set_error("allreduce_oneshot: row strides must be multiples of 8 and >= hidden"); return NVH_E_STRIDE; }
+    if (!aligned16(out) || !aligned16(x) || (packed && !aligned16(packed))) { set_error("allreduce_oneshot: pointers must be 16-byte aligned"); return NVH_E_ALIGN; }
+    const size_t need = nvh_allreduce_stage_bytes(rows, hidden);
+    if (stage_bytes < need || (stage_bytes / 2) % 16) { set_error("allreduce_oneshot: staging buffers of %zu B < required %zu B", stage_bytes, need); return NVH_E_WORKSPACE; }
+    AllReduceArgs a;
+    a.x = (const uint16_t*)x; a.out = (uint16_t*)out; a.packed = (uint16_t*)packed;
+    a.stage = stage_ptrs; a.flags = reinterpret_cast<uint32_t* const*>(flag_ptrs); a.state = (uint32_t*)state;
+    a.slot_bytes = stage_bytes / 2;
+    a.world = world; a.rank = rank; a.rows = rows; a.hidden = hidden; a.epi = epilogue;
+    a.x_stride = x_row_stride; a.out_stride = out_row_stride;
+    return launch_allreduce_oneshot(a, allreduce_blocks(rows, hidden), (hipStream_t)stream);
+}
 
 }  // extern "C"

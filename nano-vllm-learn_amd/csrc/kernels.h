@@ -126,6 +126,23 @@ __host__ __device__ inline int64_t pack_index(int row, int col, int cols) {
     return ((((int64_t)(row >> 4) * (cols >> 5) + (col >> 5)) * 64 + (((col >> 3) & 3) << 4) + (row & 15)) << 3) + (col & 7);
 }
 
+// one-shot all-reduce over IPC-mapped peer buffers (allreduce_oneshot.hip)
+enum { AR_EPI_NONE = 0, AR_EPI_RESIDUAL_ADD = 1 };       // == NVH_AR_EPI_* in nvh_attn.h
+constexpr int AR_MAX_BLOCKS = 32;                        // workgroups per launch at most: the stride of a flag table row
+struct AllReduceArgs {
+    const uint16_t* x;           // [rows, hidden] bf16: this rank's partial sums, row stride x_stride
+    uint16_t* out;               // NONE: the reduced rows; RESIDUAL_ADD: the residual stream, updated in place; row stride out_stride
+    uint16_t* packed;            // RESIDUAL_ADD, nullable: the updated rows again in MFMA-fragment order (pack_index)
+    void* const* stage;          // device array [world]: staging buffers (2 slots of slot_bytes each), own at [rank], peers IPC-mapped
+    uint32_t* const* flags;      // device array [world]: flag tables [world][AR_MAX_BLOCKS] uint32, own at [rank]
+    uint32_t* state;             // local: [0] epoch of the last finished call, [1] finished workgroups of the running one, [2] failed epoch
+    size_t slot_bytes;
+    int world, rank, rows, hidden, epi;
+    int64_t x_stride, out_stride;
+};
+int allreduce_blocks(int rows, int hidden);
+int launch_allreduce_oneshot(const AllReduceArgs& a, int blocks, hipStream_t stream);
+
 struct PrefillArgs {
     void* out;                   // [Tq, H, D]
     const uint16_t* q;           // [Tq, H, D], row stride q_row_stride

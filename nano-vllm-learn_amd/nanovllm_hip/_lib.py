@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("NVH_LIB_PATH") or os.path.join(_HERE, "lib", "libnvh_
 
 NVH_BF16 = 0
 NVH_F32 = 1
+IPC_HANDLE_BYTES = 64                                                         # NVH_COMM_IPC_HANDLE_BYTES
+AR_EPI_NONE, AR_EPI_RESIDUAL_ADD = 0, 1
 
 class LinearDesc(ctypes.Structure):
     """nvh_linear_desc (include/nvh_attn.h)."""
@@ -68,6 +70,15 @@ _SIGS = {
     "nvh_linear_small_m_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
     "nvh_pack_index": (ctypes.c_int64, [ctypes.c_int] * 3),
     "nvh_linear_small_m_candidate_groups": (ctypes.c_int, [ctypes.c_int] * 2),
+    "nvh_comm_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]),
+    "nvh_comm_free": (ctypes.c_int, [ctypes.c_void_p]),
+    "nvh_comm_ipc_export": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "nvh_comm_ipc_open": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "nvh_comm_ipc_close": (ctypes.c_int, [ctypes.c_void_p]),
+    "nvh_allreduce_stage_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    "nvh_allreduce_flag_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "nvh_allreduce_oneshot": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_size_t,
+                                                                        ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "nvh_greedy_advance_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int] +
                                       [ctypes.c_void_p] * 5 + [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64,
                                                                 ctypes.c_void_p, ctypes.c_void_p]),

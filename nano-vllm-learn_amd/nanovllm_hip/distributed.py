@@ -1,0 +1,159 @@
+"""Tensor-parallel all-reduce of the row-parallel projections: where the reference calls `dist.all_reduce(y)` in
+RowParallelLinear.forward (nanovllm/layers/linear.py:185-190; NCCL), this package offers two interchangeable paths, chosen ONCE at
+start-up, identically on every rank:
+
+  * `OneShotAllReduce` — the MI355X-native path for decode-sized messages: every rank maps every peer's staging buffer and flag
+    table through hipIpc handles and the HIP kernel behind `nvh_allreduce_oneshot` (csrc/allreduce_oneshot.hip) reads the p-1
+    peers over p-1 distinct xGMI links at once, sums in rank order and applies the residual add that follows (layernorm.py:35-36)
+    in the same launch.  Capture-safe: it can sit inside the HIP graph of a decode step.
+  * RCCL through torch.distributed (`backend="nccl"`), the fallback: used when the one-shot set-up is not available on some rank
+    (no IPC between the processes, a message larger than the staging buffers, a world of one).
+
+The handle exchange uses the process group that already exists (all_gather_object: a host-side, one-time exchange of 64-byte
+handles); the data path never touches torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import AR_EPI_NONE, AR_EPI_RESIDUAL_ADD, IPC_HANDLE_BYTES, NVH_BF16
+
+
+class OneShotAllReduce:
+    """All-reduce (sum) of [rows <= max_rows, hidden] bf16 tensors over the ranks of `group`, one process per GPU."""
+
+    def __init__(self, max_rows: int, hidden: int, group=None, device=None):
+        assert dist.is_initialized(), "needs an initialised process group (one process per GPU)"
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.max_rows, self.hidden = max_rows, hidden
+        lib = _lib.load()
+        self._lib = lib
+        self.stage_bytes = int(lib.nvh_allreduce_stage_bytes(max_rows, hidden))
+        flag_bytes = int(lib.nvh_allreduce_flag_bytes(self.world))
+        assert self.stage_bytes > 0 and flag_bytes > 0, "hidden must be a positive multiple of 8"
+        self._own, self._opened = [], []
+        # Two phases, each closed by a collective that EVERY rank reaches whether its own part worked or not: a rank whose HIP
+        # call fails must not leave the others blocked in the handle exchange.
+        stage = flags = state = None
+        handles, err = None, None
+        with torch.cuda.device(self.device):
+            try:
+                stage, flags, state = (self._alloc(n) for n in (self.stage_bytes, flag_bytes, 64))
+                handles = (self._export(stage), self._export(flags))
+            except Exception as e:
+                err = f"rank {self.rank}: {type(e).__name__}: {e}"
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, (err, handles), group=group)      # host-side, once: 2 x 64 bytes per rank
+            errs = [g[0] for g in gathered if g[0]]
+            stage_ptrs, flag_ptrs = [], []
+            if not errs:
+                try:
+                    for r, (_, (hs, hf)) in enumerate(gathered):
+                        stage_ptrs.append(stage if r == self.rank else self._open(hs))
+                        flag_ptrs.append(flags if r == self.rank else self._open(hf))
+                except Exception as e:
+                    err = f"rank {self.rank}: {type(e).__name__}: {e}"
+            gathered2 = [None] * self.world
+            dist.all_gather_object(gathered2, err, group=group)
+            errs = [g for g in gathered2 if g]
+            if errs:
+                self.close()
+                raise RuntimeError("one-shot all-reduce set-up failed: " + "; ".join(errs))
+        self._state = state
+        self._stage_tab = torch.tensor(stage_ptrs, dtype=torch.int64, device=self.device)     # void* const [world]
+        self._flag_tab = torch.tensor(flag_ptrs, dtype=torch.int64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        dist.barrier(group=group)                                               # nobody launches before every table is up
+
+    # ---- set-up helpers (host-synchronous HIP calls behind the C ABI)
+    def _alloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _lib.check(self._lib.nvh_comm_alloc(ctypes.byref(p), nbytes), "nvh_comm_alloc")
+        self._own.append(p.value)
+        return p.value
+
+    def _export(self, ptr):
+        buf = (ctypes.c_ubyte * IPC_HANDLE_BYTES)()
+        _lib.check(self._lib.nvh_comm_ipc_export(ptr, buf), "nvh_comm_ipc_export")
+        return bytes(buf)
+
+    def _open(self, handle):
+        p = ctypes.c_void_p()
+        _lib.check(self._lib.nvh_comm_ipc_open(handle, ctypes.byref(p)), "nvh_comm_ipc_open")
+        self._opened.append(p.value)
+        return p.value
+
+    def close(self):
+        """Unmap the peers' buffers and free this rank's (after every rank has stopped calling)."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize(self.device)
+        for p in self._opened:
+            self._lib.nvh_comm_ipc_close(p)
+        for p in self._own:
+            self._lib.nvh_comm_free(p)
+        self._opened, self._own = [], []
+
+    # ---- data path
+    def fits(self, x) -> bool:
+        return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == self.hidden and x.shape[0] <= self.max_rows
+                and x.stride(1) == 1 and x.stride(0) % 8 == 0)
+
+    def _launch(self, out, x, packed, epilogue):
+        rc = self._lib.nvh_allreduce_oneshot(out.data_ptr(), x.data_ptr(), packed.data_ptr() if packed is not None else None,
+                                             self._stage_tab.data_ptr(), self._flag_tab.data_ptr(), self._state, self.world, self.rank,
+                                             x.shape[0], self.hidden, x.stride(0), out.stride(0), self.stage_bytes, epilogue, NVH_BF16,
+                                             torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "nvh_allreduce_oneshot")
+
+    def all_reduce(self, x):
+        """In place: x <- sum over ranks (the call of linear.py:188-189)."""
+        assert self.fits(x)
+        self._launch(x, x, None, AR_EPI_NONE)
+        return x
+
+    def all_reduce_residual_add(self, y, residual, packed=None):
+        """residual <- bf16(residual + bf16(sum over ranks of y)), and the updated rows in fragment order into `packed` (flat bf16
+        buffer of ceil(rows / 16) * 16 * hidden elements) if given: all-reduce + the add of layernorm.py:35-36 in one launch."""
+        assert self.fits(y) and residual.shape == y.shape and residual.dtype == torch.bfloat16 and residual.stride(1) == 1
+        if packed is not None:
+            assert packed.dtype == torch.bfloat16 and packed.is_contiguous() and packed.numel() >= ((y.shape[0] + 15) // 16) * 16 * self.hidden
+        self._launch(residual, y, packed, AR_EPI_RESIDUAL_ADD)
+        return residual
+
+    def failed_epoch(self) -> int:
+        """0, or the call number at which a peer failed to show up (the kernel then wrote NaN rows instead of hanging)."""
+        st = (ctypes.c_uint32 * 16)()
+        hip = ctypes.CDLL("libamdhip64.so.7")
+        torch.cuda.synchronize(self.device)
+        hip.hipMemcpy(st, ctypes.c_void_p(self._state), 64, 2)                  # hipMemcpyDeviceToHost
+        return int(st[2])
+
+
+_comm = None          # process-wide choice, made once by init_tensor_parallel_comm
+
+
+def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_oneshot: bool = True):
+    """Choose the all-reduce path for this process group, the same on every rank: one-shot over IPC if EVERY rank managed to set it
+    up, RCCL otherwise.  Returns the OneShotAllReduce or None (= use dist.all_reduce)."""
+    global _comm
+    _comm = None
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1 and prefer_oneshot and torch.cuda.is_available()):
+        return None
+    try:
+        _comm = OneShotAllReduce(max_rows, hidden, group=group)              # raises on EVERY rank if it failed on any (agreed inside)
+    except RuntimeError as e:                                                    # e.g. IPC not available between these processes
+        import warnings
+        warnings.warn(f"{e}; falling back to RCCL (dist.all_reduce)")
+        _comm = None
+    return _comm
+
+
+def tensor_parallel_comm():
+    return _comm

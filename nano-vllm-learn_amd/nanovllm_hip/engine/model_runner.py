@@ -101,6 +101,12 @@ class ModelRunner:
         self.model.eval()
         self.num_kvcache_blocks = num_kvcache_blocks
         self.allocate_kv_cache()
+        # tensor parallel: choose the all-reduce path once, the same on every rank (one-shot over IPC-mapped peer buffers for the
+        # decode-sized messages, RCCL otherwise / as the fallback); NVH_ALLREDUCE=rccl keeps everything on RCCL
+        self.comm = None
+        if self.world_size > 1 and self.device.type == "cuda":
+            from ..distributed import init_tensor_parallel_comm
+            self.comm = init_tensor_parallel_comm(64, cfg.hidden_size, prefer_oneshot=os.environ.get("NVH_ALLREDUCE", "oneshot") != "rccl")
 
     def allocate_kv_cache(self):
         cfg = self.cfg
@@ -208,17 +214,21 @@ class DecodeSession:
             self.hidden_in_p = torch.zeros(((b + 15) // 16) * 16 * hid, dtype=torch.bfloat16, device=dev)
             self._refresh_embedding()
         self.graph = None
-        if use_graph and runner.world_size > 1 and dist.get_backend() != "nccl" and not os.environ.get("NVH_TRY_CAPTURE"):
-            use_graph = False                                 # only RCCL collectives can be captured; anything else runs eager steps
-                                                              # (NVH_TRY_CAPTURE=1: attempt anyway, to exercise the recovery path)
+        # Graph or eager is decided BEFORE any capture attempt.  Capturable: a single rank; several ranks whose step contains only
+        # this library's own launches (the one-shot all-reduce) or RCCL collectives.  Anything else (e.g. a gloo rehearsal without
+        # the one-shot path) runs eager steps.  A capture that fails all the same is FATAL: ROCm leaves the stream invalidated
+        # (hipStreamEndCapture answers 908, every later call on it fails), and with a collective inside the other ranks would be
+        # left on poisoned streams too — the process reports why and stops; a supervisor may start a fresh one.
+        if use_graph and runner.world_size > 1 and runner.comm is None and dist.get_backend() != "nccl":
+            use_graph = False
         if use_graph:
             try:
                 self._capture()
-            except Exception as e:                            # e.g. a collective that cannot be captured on this stack
-                import warnings
-                warnings.warn(f"HIP-graph capture of the decode step failed ({type(e).__name__}: {e}); running eager steps")
-                self.graph = None
-                self._restore(self._capture_saved)
+            except Exception as e:
+                raise RuntimeError(
+                    f"HIP-graph capture of the decode step failed ({type(e).__name__}: {e}).  The capturing stream is invalidated and "
+                    "cannot be used again in this process: restart with enforce_eager=True (bench.py --eager) or fix the uncapturable "
+                    "call.  Not continuing on a poisoned stream.") from e
 
     def _advance(self, next_tokens):
         """Device-side postprocess + prepare_decode for the following step."""

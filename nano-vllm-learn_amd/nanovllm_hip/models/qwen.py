@@ -67,6 +67,29 @@ def _tp():
     return 0, 1
 
 
+def tp_all_reduce(x):
+    """The all-reduce of RowParallelLinear.forward (layers/linear.py:185-190), in place: the one-shot IPC kernel when the process
+    chose it at start-up and the message fits its staging buffers (decode sizes), RCCL through torch.distributed otherwise."""
+    from ..distributed import tensor_parallel_comm
+    comm = tensor_parallel_comm()
+    if comm is not None and comm.fits(x):
+        return comm.all_reduce(x)
+    dist.all_reduce(x)
+    return x
+
+
+def tp_all_reduce_residual_add_pack(y, residual, packed):
+    """all-reduce(y) -> residual += sum -> fragment-packed copy: ONE launch on the one-shot path, RCCL + nvh_residual_add_pack
+    otherwise (same rounding points: the sum is rounded to bf16 once, then added to the residual stream in fp32)."""
+    from .. import ops
+    from ..distributed import tensor_parallel_comm
+    comm = tensor_parallel_comm()
+    if comm is not None and comm.fits(y):
+        return comm.all_reduce_residual_add(y, residual, packed)
+    dist.all_reduce(y)
+    return ops.residual_add_pack(residual, y, packed)
+
+
 def tp_partition(num_heads, num_kv_heads, tp, rank):
     """Head ranges of one tensor-parallel rank: (q_start, q_count, kv_start, kv_count).
 
@@ -192,7 +215,7 @@ class QwenAttention(nn.Module):
                                             self.k_norm.weight if self.qk_norm else None, self.q_norm.eps if self.qk_norm else 1e-6)
             out = linear(o, self.o_proj.weight)
             if _tp()[1] > 1:
-                dist.all_reduce(out)
+                tp_all_reduce(out)
             return out
         q, k, v = qkv.split([self.q_size, self.kv_size, self.kv_size], dim=-1)
         if self.qk_norm:
@@ -202,7 +225,7 @@ class QwenAttention(nn.Module):
         o = self.attn(q, k, v)                                   # qwen3.py:117 — the hot path
         out = linear(o, self.o_proj.weight)
         if _tp()[1] > 1:
-            dist.all_reduce(out)                                 # layers/linear.py:188-189 (RCCL over xGMI)
+            tp_all_reduce(out)                                   # layers/linear.py:188-189 (one-shot over xGMI, or RCCL)
         return out
 
 
@@ -228,7 +251,7 @@ class QwenMLP(nn.Module):
             act = silu_and_mul(F.linear(x, w))
         out = linear(act, self.down_proj.weight)
         if _tp()[1] > 1:
-            dist.all_reduce(out)
+            tp_all_reduce(out)
         return out
 
 
@@ -253,6 +276,25 @@ class QwenDecoderLayer(nn.Module):
 
 
 FUSED_DECODE = True          # tests flip this to compare the fused decode layer with the plain one
+
+
+class PackedResidual:
+    """What the fused decode path hands from forward() to compute_logits() / greedy_candidates(): the UN-normalised residual
+    stream (row-major) and the same rows in fragment order.  The final RMSNorm rides in the LM head's launch, so there is no
+    normalised hidden state to return; returning this object (instead of stashing the packed buffer on the module) keeps a
+    forward whose logits are never asked for from leaking into the next call."""
+    __slots__ = ("residual", "packed")
+
+    def __init__(self, residual, packed):
+        self.residual, self.packed = residual, packed
+
+    @property
+    def shape(self):
+        return self.residual.shape
+
+    @property
+    def device(self):
+        return self.residual.device
 
 
 def _fused_decode_ok(cfg, x):
@@ -337,7 +379,7 @@ class QwenForCausalLM(nn.Module):
         projections (folded weights + epilogue row scale), residual adds / SiLU*mul / RoPE+store are GEMM epilogues.
         `residual` is the running residual stream (the embedding output, updated in place); every GEMM that updates it also
         writes it in fragment order for the next GEMM (csrc/linear_stream.hip), and the MLP activation exists only in that
-        order.  The final norm belongs to the LM head's launch, so this returns the un-normalised stream and flags compute_logits."""
+        order.  The final norm belongs to the LM head's launch, so this returns the un-normalised stream as a PackedResidual."""
         from .. import ops
         from ..utils.context import get_context
         ctx = get_context()
@@ -372,10 +414,10 @@ class QwenForCausalLM(nn.Module):
                                  workspace=ws)
             else:
                 # tensor parallel: this rank's heads give a partial sum (bf16, as RowParallelLinear, layers/linear.py:185-190);
-                # all-reduce over RCCL, then the residual add + fragment-packed copy in one small launch
+                # one-shot all-reduce over IPC-mapped peer buffers with the residual add + fragment-packed copy in the SAME launch
+                # (nvh_allreduce_oneshot), or RCCL followed by one small launch when the one-shot path is not set up
                 ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="none", out=ybuf, workspace=ws)
-                dist.all_reduce(ybuf)
-                ops.residual_add_pack(residual, ybuf, resid_p)
+                tp_all_reduce_residual_add_pack(ybuf, residual, resid_p)
             ops.fused_linear(resid_p, fw["gate_up"][i], x_packed_rows=m, norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
                              epilogue="silu_mul", out_packed=act_p, want_out=False, workspace=ws)
             if tp == 1:
@@ -383,19 +425,15 @@ class QwenForCausalLM(nn.Module):
                                  workspace=ws)
             else:
                 ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="none", out=ybuf, workspace=ws)
-                dist.all_reduce(ybuf)
-                ops.residual_add_pack(residual, ybuf, resid_p)
-        self._pending_final_norm = resid_p
-        return residual
+                tp_all_reduce_residual_add_pack(ybuf, residual, resid_p)
+        return PackedResidual(residual, resid_p)
 
     def compute_logits(self, hidden_states):
         w = self.embed_tokens.weight if self.cfg.tie_word_embeddings else self.lm_head.weight
-        packed = getattr(self, "_pending_final_norm", None)
-        if packed is not None:                                        # fused decode path: final RMSNorm in the LM-head launch
-            self._pending_final_norm = None
+        if isinstance(hidden_states, PackedResidual):                 # fused decode path: final RMSNorm in the LM-head launch
             from .. import ops
             m = hidden_states.shape[0]
-            return ops.fused_linear(packed, self._folded_weights()["head"], x_packed_rows=m, norm_folded=True, norm_eps=self.norm.eps,
+            return ops.fused_linear(hidden_states.packed, self._folded_weights()["head"], x_packed_rows=m, norm_folded=True, norm_eps=self.norm.eps,
                                     workspace=self._decode_buffers(m, hidden_states.device)["ws"])
         return linear(hidden_states, w)
 
@@ -411,9 +449,9 @@ class QwenForCausalLM(nn.Module):
         """Fused decode path only: LM head + per-workgroup arg-max candidates in one launch, logits never written.  Returns
         (val [groups, stride] float32, idx int32, groups) for ops.greedy_advance_candidates, or None when this path does not
         apply (then use compute_logits)."""
-        packed = getattr(self, "_pending_final_norm", None)
-        if packed is None:
+        if not isinstance(hidden_states, PackedResidual):
             return None
+        packed = hidden_states.packed
         from .. import ops
         head = self._folded_weights()["head"]
         n, k = head.shape
@@ -425,7 +463,6 @@ class QwenForCausalLM(nn.Module):
         if "cand" not in b:
             b["cand"] = (torch.empty((groups, 64), dtype=torch.float32, device=hidden_states.device),
                          torch.empty((groups, 64), dtype=torch.int32, device=hidden_states.device))
-        self._pending_final_norm = None
         ops.fused_linear(packed, head, x_packed_rows=m, norm_folded=True, norm_eps=self.norm.eps, candidates=b["cand"], want_out=False)
         return b["cand"][0], b["cand"][1], groups
 

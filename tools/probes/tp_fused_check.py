@@ -32,7 +32,7 @@ for fused in (True, False):
     with torch.inference_mode():
         set_context(False, slot_mapping=r._dev(m["slot_mapping"]), context_lens=r._dev(m["context_lens"]), block_tables=r._dev(m["block_tables"]))
         hidden = r.model(r._dev(m["input_ids"]), r._dev(m["positions"]))
-        used_fused = getattr(r.model, "_pending_final_norm", None) is not None
+        used_fused = isinstance(hidden, qwen.PackedResidual)
         out[fused] = r.model.compute_logits(hidden).float().cpu()
         reset_context()
     if fused:

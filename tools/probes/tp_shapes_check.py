@@ -72,7 +72,7 @@ for tp, rank in ((8, 0), (8, 3), (4, 1)):
             set_context(False, slot_mapping=r._dev(m["slot_mapping"]), context_lens=r._dev(m["context_lens"]), block_tables=r._dev(m["block_tables"]))
             hidden = r.model(r._dev(m["input_ids"]), r._dev(m["positions"]))
             if fused:
-                assert getattr(r.model, "_pending_final_norm", None) is not None, "the fused layer was expected to run"
+                assert isinstance(hidden, qwen.PackedResidual), "the fused layer was expected to run"
             out[fused] = r.model.compute_logits(hidden).float().cpu()
             reset_context()
     qwen.FUSED_DECODE = True
