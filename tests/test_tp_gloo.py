@@ -59,6 +59,10 @@ def _worker(rank, world, port, cfg_kwargs, lens, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(1)
     try:
+        # without a GPU the start-up choice of the all-reduce path must come out as "torch.distributed" on every rank, without
+        # touching the HIP library (the one-shot IPC path is GPU-only; tests/test_hip_allreduce.py rehearses it on the GPU box)
+        from nanovllm_hip.distributed import init_tensor_parallel_comm, tensor_parallel_comm
+        assert init_tensor_parallel_comm(64, cfg_kwargs["hidden_size"]) is None and tensor_parallel_comm() is None
         out = _model_out(cfg_kwargs, lens)
         gathered = [torch.empty_like(out) for _ in range(world)]
         dist.all_gather(gathered, out)
