@@ -58,13 +58,20 @@ __device__ __forceinline__ float pair_in_row(float x) {
 // v_permlane16_swap vdst, src : odd 16-lane rows of vdst <-> even rows of src.
 // With vdst == src == x both halves of every pair end up in the two results, so a symmetric
 // reduction of the two results is an all-reduce over the pair (rows r, r^1 / lanes l, l^32).
+// one v_max_f32 (IEEE maxNum: the non-NaN operand wins): plain fmaxf makes hipcc canonicalise both operands first (a v_max x, x each)
+// whenever it cannot prove they are already quiet — three VALU instructions instead of one on every step of a max chain
+__device__ __forceinline__ float max2(float x, float y) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
 __device__ __forceinline__ float max_xor16(float x) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float max_xor32(float x) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return max2(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 // Reduce-scatter steps: ONE swap + ONE add folds TWO values over the pair.
 //   fold32(a, b): lanes 0..31 get a[l] + a[l+32], lanes 32..63 get b[l-32] + b[l].

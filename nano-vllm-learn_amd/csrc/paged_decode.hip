@@ -698,10 +698,10 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             float mx = sT[0][0];
 #pragma unroll
             for (int i = 1; i + 1 < 4 * NT; i += 2) mx = max3(mx, sT[i >> 2][i & 3], sT[(i + 1) >> 2][(i + 1) & 3]);
-            mx = fmaxf(mx, sT[NT - 1][3]);
+            mx = max2(mx, sT[NT - 1][3]);
             mx = max_xor16(mx);
             mx = max_xor32(mx);                                // finite: token 0 of the tile is live
-            const float m_new = fmaxf(m_run, mx * a.scale_log2);
+            const float m_new = max2(m_run, mx * a.scale_log2);
             float lsum = 0.f;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt)

@@ -258,6 +258,12 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                     for (int qs = 0; qs < QT; ++qs) sT[qs][tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[qs][st], sT[qs][tt], 0, 0, 0);
                 }
             }
+            // The max chain reads the accumulators through inline asm, which hipcc does not pad with the wait states a VALU read of
+            // a fresh MFMA result needs; one statement that takes every accumulator as an operand (so it follows every MFMA of the
+            // tile) carries them (see the same guard in paged_decode.hip, where a 16-key tile exposed the hazard).
+            if constexpr (QT == 1) asm volatile("s_nop 7" : "+v"(sT[0][0]), "+v"(sT[0][1]), "+v"(sT[0][2]), "+v"(sT[0][3]));
+            else asm volatile("s_nop 7" : "+v"(sT[0][0]), "+v"(sT[0][1]), "+v"(sT[0][2]), "+v"(sT[0][3]), "+v"(sT[1][0]), "+v"(sT[1][1]), "+v"(sT[1][2]), "+v"(sT[1][3]));
+            static_assert(QT == 1 || QT == 2, "query sub-tiles per wave");
             // ---- online softmax in the log2 domain.  Masking only where it can matter: tiles that reach past this wave's
             // first row's diagonal or past the sequence end (wave-uniform test); interior tiles skip the per-element work.
             const bool need_mask = kv0 + BN - 1 > wave_first_key || kv0 + BN > sk;
@@ -280,11 +286,11 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 mx = max3(mx, sT[qs][2][1], sT[qs][2][2]);
                 mx = max3(mx, sT[qs][2][3], sT[qs][3][0]);
                 mx = max3(mx, sT[qs][3][1], sT[qs][3][2]);
-                mx = fmaxf(mx, sT[qs][3][3]);
+                mx = max2(mx, sT[qs][3][3]);
                 mx = max_xor16(mx);
                 mx = max_xor32(mx);
                 mx *= a.scale_log2;                                              // scale > 0: max commutes with the scaling
-                const float m_new = fmaxf(m_run[qs], mx);
+                const float m_new = max2(m_run[qs], mx);
                 // rows that have seen no key yet keep m = -inf; use 0 as the reference point so exp2 stays finite
                 const float m_use = m_new == -INFINITY ? 0.f : m_new;
                 // scale-and-subtract and the row sum on element PAIRS (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue slot;
@@ -512,6 +518,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
                     sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
                 }
             }
+            asm volatile("s_nop 7" : "+v"(sT[0]), "+v"(sT[1]), "+v"(sT[2]), "+v"(sT[3]));   // wait states: MFMA results -> the asm max chain
             if (kv0 + BN - 1 > q0 + shift || kv0 + BN > sk) {                    // wave-uniform: the tile reaches the diagonal or the end
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
@@ -528,11 +535,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
             mx = max3(mx, sT[2][1], sT[2][2]);
             mx = max3(mx, sT[2][3], sT[3][0]);
             mx = max3(mx, sT[3][1], sT[3][2]);
-            mx = fmaxf(mx, sT[3][3]);
+            mx = max2(mx, sT[3][3]);
             mx = max_xor16(mx);
             mx = max_xor32(mx);
             mx *= a.scale_log2;
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = max2(m_run, mx);
             const float m_use = m_new == -INFINITY ? 0.f : m_new;                // rows that have seen no key yet
             const f32x2 sc2 = {a.scale_log2, a.scale_log2}, mm2 = {-m_use, -m_use};
             f32x2 psum2 = {0.f, 0.f};
