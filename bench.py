@@ -321,6 +321,8 @@ def main():
         del sess
         torch.cuda.empty_cache()
         prefill = {"config5_half": prefill_leg(cfg, tp, 128, 128), "s1024": prefill_leg(cfg, tp, 16, 1024, buffers=8, iters=4)}
+    from nanovllm_hip import distributed as nvh_dist
+    tp_choice = nvh_dist.last_choice
     from nanovllm_hip.models.qwen import tp_partition
     shapes = [list(tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)) for r in range(tp)]
 
@@ -340,7 +342,7 @@ def main():
                        "global_batch": args.batch, "context_first_step": ctx0, "parallelism": f"tp{tp}",
                        "collective": ((f"{dist.get_backend()} world_size {world} (torch.distributed; nccl = RCCL over xGMI); decode all-reduces: "
                                        + ("one-shot over IPC-mapped peer buffers with the residual add fused in (nvh_allreduce_oneshot), inside the HIP graph"
-                                          if engine.runner.comm is not None else "RCCL ring through torch.distributed")) if world > 1 else "none (single GPU)"),
+                                          if engine.runner.comm is not None else "RCCL ring through torch.distributed") + f" [{tp_choice}]") if world > 1 else "none (single GPU)"),
                        "heads_per_rank_q0_qn_kv0_kvn": shapes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,

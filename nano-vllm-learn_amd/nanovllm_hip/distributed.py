@@ -139,20 +139,92 @@ class OneShotAllReduce:
 _comm = None          # process-wide choice, made once by init_tensor_parallel_comm
 
 
-def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_oneshot: bool = True):
+def _self_test(comm, group) -> str | None:
+    """Run the one-shot kernel on data every rank can predict (rank r contributes a constant pattern scaled by r + 1) at three
+    sizes and both epilogues; returns None or what went wrong.  Cheap (six launches) and it turns a mis-set-up IPC mapping or
+    an unexpected visibility problem on real hardware into a clean fall-back instead of wrong tokens."""
+    world, rank, dev, hid = comm.world, comm.rank, comm.device, comm.hidden
+    for rows in (1, 17, comm.max_rows):
+        base = (torch.arange(rows * hid, dtype=torch.float32) % 61 - 30).view(rows, hid) / 16     # exactly representable in bf16
+        mine = (base * (rank + 1)).to(torch.bfloat16).to(dev)
+        acc = torch.zeros_like(base)
+        for r in range(world):
+            acc = acc + (base * (r + 1)).to(torch.bfloat16).float()
+        want = acc.to(torch.bfloat16)
+        y = mine.clone()
+        comm.all_reduce(y)
+        res = torch.ones(rows, hid, dtype=torch.bfloat16, device=dev)
+        comm.all_reduce_residual_add(mine, res)
+        torch.cuda.synchronize(dev)
+        if not torch.equal(y.cpu(), want):
+            return f"rank {rank}: all_reduce of {rows} rows differs from the rank-order sum"
+        if not torch.equal(res.cpu(), (1.0 + want.float()).to(torch.bfloat16)):
+            return f"rank {rank}: fused residual add of {rows} rows differs"
+    if comm.failed_epoch():
+        return f"rank {rank}: a peer did not show up at call {comm.failed_epoch()}"
+    return None
+
+
+def _time_us(fn, dev, group, iters=30):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize(dev)
+    dist.barrier(group=group)
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(iters):
+        fn()
+    end.record()
+    torch.cuda.synchronize(dev)
+    return start.elapsed_time(end) * 1e3 / iters
+
+
+def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_oneshot: bool = True, measure: bool = True):
     """Choose the all-reduce path for this process group, the same on every rank: one-shot over IPC if EVERY rank managed to set it
-    up, RCCL otherwise.  Returns the OneShotAllReduce or None (= use dist.all_reduce)."""
-    global _comm
-    _comm = None
+    up AND passed the self-test AND (with an RCCL group, `measure`) it is not slower than RCCL on a decode-sized message timed
+    right here, RCCL otherwise.  Returns the OneShotAllReduce or None (= use dist.all_reduce).  `last_choice` says why."""
+    global _comm, last_choice
+    _comm, last_choice = None, "torch.distributed (single rank, no GPU, or one-shot not requested)"
     if not (dist.is_initialized() and dist.get_world_size(group) > 1 and prefer_oneshot and torch.cuda.is_available()):
         return None
     try:
-        _comm = OneShotAllReduce(max_rows, hidden, group=group)              # raises on EVERY rank if it failed on any (agreed inside)
+        comm = OneShotAllReduce(max_rows, hidden, group=group)                # raises on EVERY rank if it failed on any (agreed inside)
     except RuntimeError as e:                                                    # e.g. IPC not available between these processes
         import warnings
         warnings.warn(f"{e}; falling back to RCCL (dist.all_reduce)")
-        _comm = None
+        last_choice = f"torch.distributed: {e}"
+        return None
+    problem = None
+    try:
+        problem = _self_test(comm, group)
+    except Exception as e:
+        problem = f"rank {comm.rank}: self-test raised {type(e).__name__}: {e}"
+    problems = [None] * comm.world
+    dist.all_gather_object(problems, problem, group=group)
+    problems = [p for p in problems if p]
+    note = "one-shot over IPC-mapped peer buffers (self-test passed)"
+    if not problems and measure and dist.get_backend(group) == "nccl":
+        # measure, don't guess: the decode message of this model through both paths, on this node, now
+        x = torch.zeros(min(32, max_rows), hidden, dtype=torch.bfloat16, device=comm.device)
+        t_one = _time_us(lambda: comm.all_reduce(x), comm.device, group)
+        t_rccl = _time_us(lambda: dist.all_reduce(x, group=group), comm.device, group)
+        t = torch.tensor([t_one, t_rccl], dtype=torch.float64, device=comm.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)                  # the slowest rank's view, identical everywhere
+        t_one, t_rccl = float(t[0]), float(t[1])
+        note = f"one-shot {t_one:.1f} us vs RCCL {t_rccl:.1f} us per [{x.shape[0]}, {hidden}] bf16 all-reduce (eager launches, max over ranks)"
+        if t_one > t_rccl:
+            problems = [f"slower than RCCL here: {note}"]
+    if problems:
+        import warnings
+        warnings.warn("one-shot all-reduce not used: " + "; ".join(problems))
+        comm.close()
+        last_choice = "torch.distributed: " + "; ".join(problems)
+        return None
+    _comm, last_choice = comm, note
     return _comm
+
+
+last_choice = "not initialised"
 
 
 def tensor_parallel_comm():
