@@ -323,12 +323,25 @@ __device__ __forceinline__ int32_t load_uniform_i32(const int32_t* p) {
 }
 
 // write-through store / cache-bypassing load of one float (global_store_dword / global_load_dword with sc1)
+// -DNVH_HANDOFF_FENCES (cross-check build, never shipped; tools/probes/run_fence_crosscheck.sh): the SAME hand-off in the HIP
+// memory model's textbook form — plain stores, an agent-scope release fence before the ticket, an agent-scope acquire fence
+// behind it, plain loads.  +4-5 us per launch; the parity suite is run once against it to show that the fence-free form
+// computes the same thing.
+#ifdef NVH_HANDOFF_FENCES
+__device__ __forceinline__ void st_sc1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float ld_sc1(const float* p) { return *p; }
+#define NVH_HANDOFF_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define NVH_HANDOFF_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
 __device__ __forceinline__ void st_sc1(float* p, float v) {
     __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float ld_sc1(const float* p) {
     return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+#define NVH_HANDOFF_RELEASE() do {} while (0)
+#define NVH_HANDOFF_ACQUIRE() do {} while (0)
+#endif
 
 template <int D>
 __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const DecodeArgs a, const int G) {
@@ -859,10 +872,14 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         __syncthreads();
         NVH_TSTAMP(3);
         if (tid == 0) {
+            NVH_HANDOFF_RELEASE();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             unsigned* const ctr = e_counters + (int64_t)b * p_kvh + kh;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *lds_ticket = old;
+            NVH_HANDOFF_ACQUIRE();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
         NVH_TSTAMP(4);
