@@ -245,6 +245,8 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         const int kv0 = it * BN;
         if (kv0 <= wave_last_key) {                                              // wave-uniform: tile not entirely above the diagonal
             // ---- S^T for the four 16-key tiles of both query sub-tiles: each K fragment is read once, used QT times
+            // (skipping the 16-key groups above the wave's diagonal, as the short-sequence kernel below does, measured 2-5 % SLOWER
+            // here at every S >= 256, same-box A/B: the interior tiles pay for the extra branches and live ranges)
             f32x4 sT[QT][NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -507,15 +509,26 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
             constexpr int KOFF = it * 2 * IMG, VOFF = KOFF + IMG;
             const unsigned char* const kimg = lds + KOFF;
             const int kv0 = it * BN;
+            // groups of 16 keys entirely above the sub-tile's last row's diagonal (or past the end) are not computed (wave-uniform):
+            // at S = 128 two thirds of the tile bodies are diagonal ones that need 1..4 of their 4 groups
+            int n_tt = (last_key - kv0) / 16 + 1;                                // last_key already <= sk - 1; >= 1 here
+            n_tt = n_tt < NT ? n_tt : NT;
+#ifdef NVH_PREFILL_NO_GROUP_SKIP                                                  // A/B builds only
+            n_tt = NT;
+#endif
             f32x4 sT[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                const int R = 16 * tt + lq;
+                if (tt < n_tt) {
+                    sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const int R = 16 * tt + lq;
 #pragma unroll
-                for (int st = 0; st < STEPS; ++st) {
-                    const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + R * ROWB + (((4 * st + lg) ^ chunk_swz<LPT>(R)) * 16));
-                    sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
+                    for (int st = 0; st < STEPS; ++st) {
+                        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kimg + R * ROWB + (((4 * st + lg) ^ chunk_swz<LPT>(R)) * 16));
+                        sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
+                    }
+                } else {
+                    sT[tt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
             }
             asm volatile("s_nop 7" : "+v"(sT[0]), "+v"(sT[1]), "+v"(sT[2]), "+v"(sT[3]));   // wait states: MFMA results -> the asm max chain
@@ -564,6 +577,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
             m_run = m_new;
 #pragma unroll
             for (int hh = 0; hh < BN / 32; ++hh) {
+                if (2 * hh >= n_tt) continue;                                    // wave-uniform: a dead 32-key half (p = 0)
                 u32x4 hraw, lraw;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {

@@ -1,10 +1,16 @@
-# prefill attention: default library vs tools/probes/ab/*.so, S sweep
+#!/bin/bash
+# same-box A/B of the prefill kernels: shipped library vs a variant built with EXTRA flags (default: -DNVH_PREFILL_NO_GROUP_SKIP)
 cd $GRAFT_REPO_ROOT
-for round in 1 2; do
-for v in default $(ls tools/probes/ab/*.so 2>/dev/null); do
-  if [ $v = default ]; then unset NVH_LIB_PATH; else export NVH_LIB_PATH=$GRAFT_REPO_ROOT/$v; fi
-  echo "== $v"
-  for s in 512 1024 4096; do timeout -k 10 100 python3 tools/microbench.py prefill --batch $((16384 / s)) --seq $s 2>/dev/null | grep TFLOPs | cut -c1-140; done
-  timeout -k 10 100 python3 tools/microbench.py prefill --batch 4 --seq 4096 --heads 16 --kv-heads 8 --head-dim 128 2>/dev/null | grep TFLOPs | cut -c1-140
+EXTRA=${EXTRA:-=prefill_mfma.hip:-DNVH_PREFILL_NO_GROUP_SKIP}
+python nano-vllm-learn_amd/build.py --variant /tmp/libnvh_ab.so --extra $EXTRA > /tmp/ab_build.log 2>&1 || { tail -5 /tmp/ab_build.log; exit 1; }
+for rep in 1 2; do
+for s in 128 256 512 1024 2048 4096; do
+  b=$((16384 / s > 256 ? 256 : 16384 / s))
+  a=$(timeout -k 10 100 python3 tools/microbench.py prefill --batch $b --seq $s 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['us_per_call'])")
+  v=$(NVH_LIB_PATH=/tmp/libnvh_ab.so timeout -k 10 100 python3 tools/microbench.py prefill --batch $b --seq $s 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['us_per_call'])")
+  echo "S=$s shipped $a us   variant $v us"
 done
+a=$(timeout -k 10 100 python3 tools/microbench.py prefill --batch 4 --seq 4096 --heads 16 --kv-heads 8 --head-dim 128 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['us_per_call'])")
+v=$(NVH_LIB_PATH=/tmp/libnvh_ab.so timeout -k 10 100 python3 tools/microbench.py prefill --batch 4 --seq 4096 --heads 16 --kv-heads 8 --head-dim 128 2>/dev/null | python3 -c "import sys,json; print(json.loads(sys.stdin.readline())['us_per_call'])")
+echo "16/8/128 S=4096 shipped $a us   variant $v us"
 done
