@@ -724,3 +724,49 @@ def test_chunk_handoff_extreme_geometry_under_graph_replay(H, KVH, D, background
             assert np.array_equal(got[n], got[first[ci]])
         else:
             first[ci] = n
+
+
+@pytest.mark.gpu
+def test_config1_shape_bs1_in512_out512(ops):
+    """BASELINE config 1's shape (Qwen2-0.5B, bs = 1, in = out = 512; the reference runs it with --attn-backend sdpa.math on the
+    CPU): the hip path on the same shape — one 512-token prefill through the Attention module's store + varlen call, then decode
+    calls at contexts 513, 700, 768, 1023 and 1024 (block boundary at 768 = 3 x 256) against the oracle, K/V rows appended by
+    store_kvcache on the way."""
+    H, KVH, D, bs = 14, 2, 64, 256
+    gen = torch.Generator().manual_seed(41)
+    n_in = 512
+    qkv = torch.randn(n_in, (H + 2 * KVH) * D, generator=gen).bfloat16()
+    q, k, v = qkv[:, :H * D].view(n_in, H, D), qkv[:, H * D:(H + KVH) * D].view(n_in, KVH, D), qkv[:, (H + KVH) * D:].view(n_in, KVH, D)
+    cu = np.array([0, n_in], np.int32)
+    exp = O.prefill_varlen(q.float().numpy(), k.float().numpy(), v.float().numpy(), cu, cu)
+    qd = qkv.cuda()
+    o32 = ops.flash_attn_varlen_func(qd[:, :H * D].view(n_in, H, D), qd[:, H * D:(H + KVH) * D].view(n_in, KVH, D), qd[:, (H + KVH) * D:].view(n_in, KVH, D),
+                                     n_in, dev_i32(cu), n_in, dev_i32(cu), out_dtype=torch.float32)
+    torch.cuda.synchronize()
+    assert np.abs(o32.cpu().numpy() - exp).max() <= ATOL
+    # the paged cache of the one sequence: blocks 5, 2, 7, 0 (shuffled), filled by store_kvcache as generation proceeds
+    table = [5, 2, 7, 0]
+    kc = torch.zeros(8, bs, KVH, D, dtype=torch.bfloat16, device="cuda")
+    vc = torch.zeros_like(kc)
+    slots = np.array([table[t // bs] * bs + t % bs for t in range(1024)], np.int32)
+    ops.store_kvcache(qd[:, H * D:(H + KVH) * D].view(n_in, KVH, D), qd[:, (H + KVH) * D:].view(n_in, KVH, D), kc, vc, dev_i32(slots[:n_in]))
+    new = torch.randn(512, (H + 2 * KVH) * D, generator=gen).bfloat16()
+    nd = new.cuda()
+    kc_ref, vc_ref = np.zeros((8, bs, KVH, D), np.float32), np.zeros((8, bs, KVH, D), np.float32)
+    O.store_kvcache(k.float().numpy(), v.float().numpy(), kc_ref, vc_ref, slots[:n_in])
+    bt = np.array([table], np.int32)
+    for step in range(512):                                      # token index 512 + step is appended, context becomes 513 + step
+        t = n_in + step
+        row = nd[step:step + 1]
+        ops.store_kvcache(row[:, H * D:(H + KVH) * D].view(1, KVH, D), row[:, (H + KVH) * D:].view(1, KVH, D), kc, vc, dev_i32(slots[t:t + 1]))
+        O.store_kvcache(new[step:step + 1, H * D:(H + KVH) * D].view(1, KVH, D).float().numpy(), new[step:step + 1, (H + KVH) * D:].view(1, KVH, D).float().numpy(),
+                        kc_ref, vc_ref, slots[t:t + 1])
+        ctx = t + 1
+        if ctx in (513, 700, 768, 769, 1023, 1024):
+            qs = row[:, :H * D].view(1, H, D)
+            d32 = ops.flash_attn_with_kvcache(qs, kc, vc, dev_i32([ctx]), dev_i32(bt), out_dtype=torch.float32)
+            d16 = ops.flash_attn_with_kvcache(qs, kc, vc, dev_i32([ctx]), dev_i32(bt))
+            torch.cuda.synchronize()
+            e = O.paged_decode(new[step:step + 1, :H * D].view(1, H, D).float().numpy(), kc_ref, vc_ref, np.array([ctx], np.int32), bt)
+            check_close(d32.cpu().numpy(), d16.float().cpu().numpy(), e, f"config 1 shape, decode at ctx {ctx}")
+    assert np.array_equal(kc.float().cpu().numpy(), kc_ref) and np.array_equal(vc.float().cpu().numpy(), vc_ref)
