@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NVH_VERSION 100          /* major*100 + minor */
+#define NVH_VERSION 200          /* major*100 + minor */
 
 /* dtype codes */
 #define NVH_BF16 0
