@@ -84,7 +84,7 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
                                 k_row_stride, v_row_stride, (hipStream_t)stream);
 }
 
-static constexpr size_t kDecodeTicketBytes = 65536;       // 16384 tickets
+static constexpr size_t kDecodeTicketBytes = 65536;       // 512 tickets, one per 128-byte line (pairs are split over chunks only when there are few of them)
 
 static int decode_num_splits(int hd, int max_blocks, int block_size) {
     const int split = decode_split_tokens(hd);
@@ -154,10 +154,7 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
     a.num_splits = decode_num_splits(hd, max_blocks, block_size);
     // (tickets are only drawn when a (sequence, kv head) pair is split over several workgroups, i.e. when batch * kvh is small)
     a.chunks = decode_chunks(batch, kvh, a.num_splits, chunks);
-    if (a.chunks > 1 && (size_t)batch * kvh * 4 > kDecodeTicketBytes) {
-        set_error("paged_decode: batch * kvh = %d > %zu tickets", batch * kvh, kDecodeTicketBytes / 4);
-        return NVH_E_SHAPE;
-    }
+    // (decode_chunks never splits more pairs than the header has tickets for: 512, one per 128-byte line)
     a.counters = reinterpret_cast<unsigned*>(workspace);
     a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeTicketBytes);
     a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;

@@ -45,6 +45,10 @@ namespace {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef NVH_TICKET_WORDS
+#define NVH_TICKET_WORDS 32                        // A/B builds: 1 = dense tickets (the round-1 layout)
+#endif
+constexpr int kTicketWords = NVH_TICKET_WORDS;    // uint32 words between two tiles' arrival tickets: one ticket per 128-byte line
 constexpr int SW = 4;                          // waves per workgroup
 constexpr unsigned kMultiWgs = 512;            // workgroups of a MULTI launch (the LM head): two per CU, a power of two
 constexpr int PMAX = 4;                        // pieces (2 k-steps = 64 K-elements = one 128-byte line per weight row) per wave
@@ -344,9 +348,9 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                const unsigned old = __hip_atomic_fetch_add(&e_counters[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned old = __hip_atomic_fetch_add(&e_counters[tile * kTicketWords], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (old == (unsigned)p_ksplit - 1)
-                    __hip_atomic_store(&e_counters[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
+                    __hip_atomic_store(&e_counters[tile * kTicketWords], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
                 *lds_ticket = old;
             }
             __syncthreads();
@@ -564,13 +568,14 @@ int linear_stream_candidate_groups(int n, int k) {
     return tiles > 1024 ? (int)kMultiWgs : tiles;
 }
 
-// counters [tiles] (rounded to 256 B) then partial records [tiles][ksplit][NB*MT*256 + MT*16] fp32; 0 when K needs no split
+// counters [tiles], ONE PER 128-BYTE LINE (the memory side executes the adds on one line one after the other: dense tickets made every
+// tile's last arriver queue behind its neighbours' adds), then partial records [tiles][ksplit][NB*MT*256 + MT*16] fp32; 0 when K needs no split
 size_t linear_stream_workspace_bytes(int m, int n, int k, int epi) {
     const int pieces = k / 64, ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);
     if (ksplit <= 1) return 0;
     const int nb = (epi == EPI_SILU || epi == EPI_ROPE) ? 2 : 1, mt = (m + 15) / 16;
     const int tiles = nb == 2 ? n / 32 : n / 16;
-    return (((size_t)tiles * 4 + 255) / 256) * 256 + (size_t)tiles * ksplit * (nb * mt * 256 + mt * 16) * 4;
+    return (size_t)tiles * kTicketWords * 4 + (size_t)tiles * ksplit * (nb * mt * 256 + mt * 16) * 4;
 }
 
 // Returns -100 when the call is not this kernel's (the caller falls back to skinny_gemm.hip's loop kernel).
@@ -583,7 +588,7 @@ int launch_linear_stream(const LinearArgs& a_in, hipStream_t stream) {
     const int pieces = a.K / 64;
     a.ksplit = (pieces + SW * PMAX - 1) / (SW * PMAX);
     if (a.ksplit > 1) {
-        const size_t counters_bytes = (((size_t)a.tiles * 4 + 255) / 256) * 256;
+        const size_t counters_bytes = (size_t)a.tiles * kTicketWords * 4;
         const int nb = (a.epi == EPI_SILU || a.epi == EPI_ROPE) ? 2 : 1, mt = (a.M + 15) / 16;
         if (!a.ws_raw || a.ws_bytes < counters_bytes + (size_t)a.tiles * a.ksplit * (nb * mt * 256 + mt * 16) * 4) return -100;
         a.counters = reinterpret_cast<unsigned*>(a.ws_raw);

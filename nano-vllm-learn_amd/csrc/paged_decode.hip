@@ -265,6 +265,11 @@ __global__ __launch_bounds__(WAVES * 64) void paged_decode_split_valu_kernel(con
 //                 bits and the 1e-3 parity bar holds at |o| ~ 3); A = V^T by ds_read_b64_tr_b16.
 //   The 4 waves merge through LDS (aliasing the wave's K image) into one partial per workgroup.
 constexpr int MW = 4;
+#ifndef NVH_TICKET_WORDS
+#define NVH_TICKET_WORDS 32                      // A/B builds: 1 = dense tickets (the round-1 layout)
+#endif
+constexpr int kTicketStride = NVH_TICKET_WORDS; // uint32 words between the tickets of two (sequence, kv head) pairs (= 128 bytes)
+constexpr int kMaxSplitPairs = 65536 / (4 * kTicketStride);   // tickets in the workspace's 64 KiB header: 512
 
 template <int D>
 struct MGeo {
@@ -874,7 +879,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         if (tid == 0) {
             NVH_HANDOFF_RELEASE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            unsigned* const ctr = e_counters + (int64_t)b * p_kvh + kh;
+            // one ticket per 128-byte line: the memory side executes the adds on one line one after the other (~12 ns each); with
+            // dense tickets the 16-32 pairs that share a line made every pair's last arriver queue behind all their adds
+            unsigned* const ctr = e_counters + ((int64_t)b * p_kvh + kh) * kTicketStride;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *lds_ticket = old;
@@ -1061,6 +1068,7 @@ static int device_cus() {
 // workgroups per (sequence, kv head): one wave of workgroups over the chip, at most one per pass; `forced` > 0 (the
 // variant entry point, tests and A/B runs) overrides the choice
 int decode_chunks(int batch, int kvh, int num_splits, int forced) {
+    if ((int64_t)batch * kvh > kMaxSplitPairs) return 1;       // (more pairs than tickets: far more than CUs anyway)
     const int cus = device_cus();
     int c = forced > 0 ? forced : (cus + batch * kvh / 2) / (batch * kvh);
     if (c < 1) c = 1;
