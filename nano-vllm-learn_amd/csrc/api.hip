@@ -98,7 +98,8 @@ size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int 
     const size_t parts = (size_t)batch * h * decode_num_splits(hd, max_blocks, block_size);
     // a fixed header of arrival tickets (one per (sequence, kv head); the SAME bytes whatever the shape, so that one
     // workspace serves calls of different shapes), then the partial records
-    return kDecodeTicketBytes + parts * (size_t)(hd + 2) * sizeof(float);
+    // (twice the packed size: chunk records are padded to 256-byte boundaries, at most a factor two at one query head per kv head)
+    return kDecodeTicketBytes + 2 * parts * (size_t)(hd + 2) * sizeof(float);
 }
 
 static int paged_decode_impl(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,

@@ -268,6 +268,9 @@ constexpr int MW = 4;
 #ifndef NVH_TICKET_WORDS
 #define NVH_TICKET_WORDS 32                      // A/B builds: 1 = dense tickets (the round-1 layout)
 #endif
+#ifndef NVH_REC_ALIGN
+#define NVH_REC_ALIGN 64                         // floats; A/B builds: 1 = records packed back to back (the round-1 layout)
+#endif
 constexpr int kTicketStride = NVH_TICKET_WORDS; // uint32 words between the tickets of two (sequence, kv head) pairs (= 128 bytes)
 constexpr int kMaxSplitPairs = 65536 / (4 * kTicketStride);   // tickets in the workspace's 64 KiB header: 512
 
@@ -858,7 +861,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     }
     NVH_TSTAMP(1);
     if (live_chunks > 1) {
-        const int rec = G * (D + 2);                          // floats per record: O[G][D], max[G], sum[G]
+        // floats per record: O[G][D], max[G], sum[G], padded so that every record starts on a 256-byte boundary (a wave's store
+        // instruction is 256 contiguous bytes: whole lines, none shared with another workgroup's record)
+        const int rec = (G * (D + 2) + NVH_REC_ALIGN - 1) / NVH_REC_ALIGN * NVH_REC_ALIGN;
         float* const recs = e_ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
         float* const mine = recs + (int64_t)split * rec;
 #pragma unroll

@@ -40,7 +40,7 @@ def test_workspace_is_pure_function_of_static_shapes(lib):
     assert lib.nvh_paged_decode_workspace(64, 14, 64, 16, 256) - hdr == 2 * (a - hdr)
     assert lib.nvh_paged_decode_workspace(32, 14, 96, 16, 256) == 0          # unsupported head_dim
     # partial = (D + 2) floats per (row, head, split)
-    assert (a - hdr) % ((64 + 2) * 4 * 32 * 14) == 0
+    assert (a - hdr) % ((64 + 2) * 4 * 32 * 14) == 0 and (a - hdr) // ((64 + 2) * 4 * 32 * 14) == 2 * 16
 
 
 def test_argument_validation_without_gpu(lib):

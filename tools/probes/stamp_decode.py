@@ -35,7 +35,9 @@ def main():
     q = torch.randn(b, h, d, device="cuda", dtype=torch.bfloat16)
     out = torch.empty_like(q)
     nsplit = (nblk * bs + 255) // 256
-    ws = torch.zeros(65536 + b * h * nsplit * (d + 2) * 4, dtype=torch.uint8, device="cuda")   # ticket header + partial records
+    lib.nvh_paged_decode_workspace.restype = ctypes.c_size_t
+    lib.nvh_paged_decode_workspace.argtypes = [ctypes.c_int] * 5
+    ws = torch.zeros(lib.nvh_paged_decode_workspace(b, h, d, nblk, bs), dtype=torch.uint8, device="cuda")   # ticket header + chunk records
     waves = 8 if d == 64 else 4                                       # waves per workgroup of the chunked kernel
     stamps = torch.zeros(b * kvh * nsplit * waves * 8, dtype=torch.int64, device="cuda")
     lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
