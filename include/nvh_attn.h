@@ -100,11 +100,12 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
  *   NVH_DECODE_CHUNKED     one launch: MFMA tiles over the GQA group, split-KV passes dealt to `chunks` workgroups per
  *                          (sequence, kv head), last-arriver combine.  waves: 0 / 8 = eight waves per workgroup at hd 64, 4 = four.
  *                          chunks: 0 = one wave of workgroups over the device's CUs, > 0 = that many (clamped to the passes).
+ *   NVH_DECODE_CHUNKED_P128  the chunked kernel with 128-token passes at hd 64 (16-token wave tiles; hd 128 already works that way)
  *   NVH_DECODE_SPLIT_MFMA  the single-pass MFMA split kernel + a combine launch (flash-decoding in two launches).
  *   NVH_DECODE_SPLIT_VALU  north_star's literal form: VALU dot products with wavefront-level (DPP / permlane) max and sum
  *                          reductions, no MFMA; groups of at most 8 query heads per kv head; + the combine launch.
  */
-enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2 };
+enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2, NVH_DECODE_CHUNKED_P128 = 3 };
 int nvh_paged_decode_variant(int variant, int waves, int chunks, void* out, const void* q, const void* k_cache, const void* v_cache,
                              const int32_t* block_tables, const int32_t* context_lens,
                              int batch, int h, int kvh, int hd, int block_size, int max_blocks,

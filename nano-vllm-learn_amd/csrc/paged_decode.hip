@@ -543,7 +543,7 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //     (sequence, kv head) merges all records (sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
 //     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
 //     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
-template <int D, int NW>
+template <int D, int NW, int PASS = MGeo<D>::SPLIT>
 __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     // the operands on the way to the first DMA come first and flat: with -amdgpu-kernarg-preload-count they are in SGPRs when the
     // wave starts (14 user SGPRs), instead of behind a kernarg s_load; the rest of the descriptor follows by reference
@@ -554,7 +554,9 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     // 16-token (D=128) tiles, two waves per SIMD covering each other's LDS / MFMA latencies, same LDS footprint.  A 16-token tile
     // contracts P V over 16 keys with v_mfma_f32_16x16x16_bf16 (one transposed V read per dim tile) instead of 32 with 16x16x32.
     constexpr int MW = NW;
-    constexpr int SPLIT = MGeo<D>::SPLIT, WT = SPLIT / NW;
+    // PASS = tokens of one pass of the workgroup (default 256 at D = 64, 128 at D = 128).  D = 64 with PASS = 128 (16-token wave tiles,
+    // the k = 16 MFMA) deals a context in half-size passes: chunks whose pass counts differ by one then differ by 128 tokens, not 256
+    constexpr int SPLIT = PASS, WT = SPLIT / NW;
     constexpr int LPT = D / 8, TPI = 64 / LPT, NI = WT / TPI, ROWB = D * 2, NT = WT / 16, NHALF = WT / 32;
     constexpr int STEPS = D / 32, DT = D / 16, QI = 16 / TPI, IMG = WT * ROWB;
     constexpr int WAVES = NW;
@@ -1035,6 +1037,13 @@ int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
     const int waves = a.waves == 4 ? 4 : (a.waves == 8 ? 8 : (D == 64 ? 8 : NVH_D128_WAVES));
     dim3 grid(a.kvh, a.batch, a.chunks);
     const int bs_shift = (a.block_size & (a.block_size - 1)) == 0 ? __builtin_ctz(a.block_size) : -1;
+    if constexpr (D == 64) {
+        if (a.pass_tokens == 128) {                            // half-size passes (nvh_paged_decode_variant: NVH_DECODE_CHUNKED_P128)
+            hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8, 128>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
+                               a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
+            return check_launch("paged_decode_chunked");
+        }
+    }
     if (waves == 8) {
         hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
                            a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);

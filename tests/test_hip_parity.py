@@ -85,6 +85,7 @@ VARIANTS = {
     "chunked_c1": dict(variant="chunked", chunks=1),
     "chunked_c3": dict(variant="chunked", chunks=3),
     "chunked_c16_w4": dict(variant="chunked", chunks=16, waves=4),
+    "chunked_p128": dict(variant="chunked_p128"),            # D = 64: 128-token passes of 16-token wave tiles
     "split_mfma": dict(variant="split_mfma"),
     "split_valu": dict(variant="split_valu"),
 }
