@@ -272,14 +272,14 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
 #pragma unroll
             for (int qs = 0; qs < QT; ++qs) {
                 if (need_mask) {
+                    // element (tt, r) of this lane is key kv0 + 16 tt + 4 lg + r; it is visible iff key <= min(q_pos, sk - 1), i.e. iff the
+                    // CONSTANT 16 tt + r is <= a per-lane limit: one compare against an inline constant + one select per element
                     const int q_pos = my_q[qs] + shift;                          // last key this lane's query may see
+                    const int limit = (q_pos < sk - 1 ? q_pos : sk - 1) - kv0 - 4 * lg;
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int key = kv0 + 16 * tt + 4 * lg + r;
-                            sT[qs][tt][r] = (key <= q_pos && key < sk) ? sT[qs][tt][r] : -INFINITY;
-                        }
+                        for (int r = 0; r < 4; ++r) sT[qs][tt][r] = (16 * tt + r <= limit) ? sT[qs][tt][r] : -INFINITY;
                 }
                 float mx = max3(sT[qs][0][0], sT[qs][0][1], sT[qs][0][2]);
                 mx = max3(mx, sT[qs][0][3], sT[qs][1][0]);
@@ -533,13 +533,11 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
             }
             asm volatile("s_nop 7" : "+v"(sT[0]), "+v"(sT[1]), "+v"(sT[2]), "+v"(sT[3]));   // wait states: MFMA results -> the asm max chain
             if (kv0 + BN - 1 > q0 + shift || kv0 + BN > sk) {                    // wave-uniform: the tile reaches the diagonal or the end
+                const int limit = (q_pos < sk - 1 ? q_pos : sk - 1) - kv0 - 4 * lg;     // see the tiled kernel: constant <= per-lane limit
 #pragma unroll
                 for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = kv0 + 16 * tt + 4 * lg + r;
-                        sT[tt][r] = (key <= q_pos && key < sk) ? sT[tt][r] : -INFINITY;
-                    }
+                    for (int r = 0; r < 4; ++r) sT[tt][r] = (16 * tt + r <= limit) ? sT[tt][r] : -INFINITY;
             }
             float mx = max3(sT[0][0], sT[0][1], sT[0][2]);
             mx = max3(mx, sT[0][3], sT[1][0]);
