@@ -93,11 +93,18 @@ __device__ __forceinline__ int chunk_swz_v(int row) {
     return LPT == 8 ? (row & 6) : ((2 * row) & 14);
 }
 
-// one v_cvt_pk_bf16_f32 (round to nearest even): {lo half = a, hi half = b}
+// one v_cvt_pk_bf16_f32 (round to nearest even): {lo half = a, hi half = b}.  A vector conversion, not inline asm: hipcc pads every
+// asm statement whose result the next VALU instruction reads with an s_nop, 40 of them per tile here
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+#ifdef NVH_CVT_ASM                                                                 // A/B builds only: the round-1 form
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
+#else
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2v));
+#endif
 }
 
 template <int D, bool PAGED, int QT>

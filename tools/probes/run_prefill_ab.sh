@@ -1,7 +1,7 @@
 #!/bin/bash
 # same-box A/B of the prefill kernels: shipped library vs a variant built with EXTRA flags (default: -DNVH_PREFILL_NO_GROUP_SKIP)
 cd $GRAFT_REPO_ROOT
-EXTRA=${EXTRA:-=prefill_mfma.hip:-DNVH_PREFILL_NO_GROUP_SKIP}
+EXTRA=${EXTRA:-=prefill_mfma.hip:-DNVH_CVT_ASM}
 python nano-vllm-learn_amd/build.py --variant /tmp/libnvh_ab.so --extra $EXTRA > /tmp/ab_build.log 2>&1 || { tail -5 /tmp/ab_build.log; exit 1; }
 for rep in 1 2; do
 for s in 128 256 512 1024 2048 4096; do
