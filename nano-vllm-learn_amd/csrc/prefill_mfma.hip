@@ -572,11 +572,13 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
                     sT[tt][r + 1] = e[1];
                     psum2 += e;
                 }
-            if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {              // some row's max moved: rescale (wave-uniform branch)
-                const float alpha = fast_exp2(m_run - m_use);                    // m_run = -inf -> 0
-                l_run *= alpha;
+            if constexpr (it > 0) {                                              // (a task's first tile starts from o = l = 0: nothing to rescale)
+                if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {          // some row's max moved: rescale (wave-uniform branch)
+                    const float alpha = fast_exp2(m_run - m_use);                // m_run = -inf -> 0
+                    l_run *= alpha;
 #pragma unroll
-                for (int tt = 0; tt < DT; ++tt) o[tt] *= alpha;
+                    for (int tt = 0; tt < DT; ++tt) o[tt] *= alpha;
+                }
             }
             l_run += psum2[0] + psum2[1];
             m_run = m_new;
