@@ -67,7 +67,8 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
 /*
  * Bytes of caller-owned scratch nvh_paged_decode needs; a pure function of the static shapes so it can be
  * allocated once before graph capture.  Layout: a fixed 64 KiB header of arrival tickets (one uint32 per
- * (sequence, kv head)), then the partial records of the context chunks.  The caller ZERO-FILLS the buffer once
+ * (sequence, kv head), each on a 128-byte line of its own: 512 pairs can be split over several workgroups, far more than the
+ * device has CUs for), then the partial records of the context chunks (each padded to a 256-byte boundary).  The caller ZERO-FILLS the buffer once
  * (hipMemset / torch.zeros); every launch returns its tickets to zero, so the buffer is reusable across calls,
  * shapes and graph replays without further clearing.  ONE launch at a time per workspace: calls that may run concurrently
  * (different streams) need a workspace each; a launch that was aborted mid-flight leaves the tickets undefined (zero-fill again).
