@@ -337,6 +337,7 @@ int64_t nvh_pack_index(int row, int col, int cols);
  *                  updated rows again in fragment order (nvh_pack_index) for the next nvh_linear_small_m_ex with x_packed
  *   stage_bytes    size of EACH rank's staging buffer (>= nvh_allreduce_stage_bytes(rows, hidden))
  *   state          uint32[16], local: [0] calls completed, [2] != 0 after a peer timed out (the epoch that failed)
+ * nvh_allreduce_status (host-synchronous: waits for the device, NOT capturable) reads those two words back.
  */
 #define NVH_COMM_IPC_HANDLE_BYTES 64
 enum { NVH_AR_EPI_NONE = 0, NVH_AR_EPI_RESIDUAL_ADD = 1 };
@@ -347,6 +348,7 @@ int nvh_comm_ipc_open(const void* handle, void** ptr);
 int nvh_comm_ipc_close(void* ptr);
 size_t nvh_allreduce_stage_bytes(int max_rows, int hidden);
 size_t nvh_allreduce_flag_bytes(int world);
+int nvh_allreduce_status(const void* state, uint32_t* calls_completed, uint32_t* failed_epoch);
 int nvh_allreduce_oneshot(void* out, const void* x, void* packed, void* const* stage_ptrs, void* const* flag_ptrs, void* state,
                           int world, int rank, int rows, int hidden, int64_t x_row_stride, int64_t out_row_stride,
                           size_t stage_bytes, int epilogue, int dtype, void* stream);

@@ -535,6 +535,16 @@ int nvh_comm_ipc_open(const void* handle, void** ptr) {
     return hip_rc("comm_ipc_open: hipIpcOpenMemHandle", hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
 }
 int nvh_comm_ipc_close(void* ptr) { return ptr ? hip_rc("comm_ipc_close", hipIpcCloseMemHandle(ptr)) : 0; }
+int nvh_allreduce_status(const void* state, uint32_t* calls_completed, uint32_t* failed_epoch) {
+    if (!state) { set_error("allreduce_status: null state"); return NVH_E_NULL; }
+    uint32_t host[4] = {0, 0, 0, 0};
+    int rc = hip_rc("allreduce_status: hipDeviceSynchronize", hipDeviceSynchronize());
+    if (!rc) rc = hip_rc("allreduce_status: hipMemcpy", hipMemcpy(host, state, sizeof(host), hipMemcpyDeviceToHost));
+    if (rc) return rc;
+    if (calls_completed) *calls_completed = host[0];
+    if (failed_epoch) *failed_epoch = host[2];
+    return 0;
+}
 
 size_t nvh_allreduce_stage_bytes(int max_rows, int hidden) {
     if (max_rows <= 0 || hidden <= 0 || hidden % 8) return 0;

@@ -77,6 +77,7 @@ _SIGS = {
     "nvh_comm_ipc_close": (ctypes.c_int, [ctypes.c_void_p]),
     "nvh_allreduce_stage_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     "nvh_allreduce_flag_bytes": (ctypes.c_size_t, [ctypes.c_int]),
+    "nvh_allreduce_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]),
     "nvh_allreduce_oneshot": (ctypes.c_int, [ctypes.c_void_p] * 6 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_size_t,
                                                                         ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "nvh_greedy_advance_candidates": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_int] +

@@ -50,12 +50,13 @@ class OneShotAllReduce:
             except Exception as e:
                 err = f"rank {self.rank}: {type(e).__name__}: {e}"
             gathered = [None] * self.world
-            dist.all_gather_object(gathered, (err, handles), group=group)      # host-side, once: 2 x 64 bytes per rank
+            dist.all_gather_object(gathered, (err, handles, self._placement()), group=group)   # host-side, once: 2 x 64 bytes per rank
             errs = [g[0] for g in gathered if g[0]]
             stage_ptrs, flag_ptrs = [], []
             if not errs:
                 try:
-                    for r, (_, (hs, hf)) in enumerate(gathered):
+                    self._check_peers([g[2] for g in gathered])                # a kernel touching an unreachable peer would fault
+                    for r, (_, (hs, hf), _) in enumerate(gathered):
                         stage_ptrs.append(stage if r == self.rank else self._open(hs))
                         flag_ptrs.append(flags if r == self.rank else self._open(hf))
                 except Exception as e:
@@ -73,6 +74,25 @@ class OneShotAllReduce:
         dist.barrier(group=group)                                               # nobody launches before every table is up
 
     # ---- set-up helpers (host-synchronous HIP calls behind the C ABI)
+    def _placement(self):
+        import os
+        import socket
+        vis = tuple(os.environ.get(k, "") for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        return (socket.gethostname(), vis, self.device.index if self.device.index is not None else torch.cuda.current_device())
+
+    def _check_peers(self, placements):
+        """Refuse (cleanly, before any kernel runs) a group the peer mappings cannot serve: ranks on another host, or a peer GPU
+        this device has no peer access to.  Where the ranks see different device lists the ordinals cannot be compared and the
+        check is left to hipIpcOpenMemHandle and the start-up self-test."""
+        host, vis, mine = placements[self.rank]
+        for r, (h, v, theirs) in enumerate(placements):
+            if r == self.rank:
+                continue
+            if h != host:
+                raise RuntimeError(f"rank {r} runs on host {h}, this rank on {host}: IPC mappings need one node")
+            if v == vis and theirs != mine and not torch.cuda.can_device_access_peer(mine, theirs):
+                raise RuntimeError(f"device {mine} has no peer access to device {theirs} (rank {r})")
+
     def _alloc(self, nbytes):
         p = ctypes.c_void_p()
         _lib.check(self._lib.nvh_comm_alloc(ctypes.byref(p), nbytes), "nvh_comm_alloc")
@@ -129,11 +149,10 @@ class OneShotAllReduce:
 
     def failed_epoch(self) -> int:
         """0, or the call number at which a peer failed to show up (the kernel then wrote NaN rows instead of hanging)."""
-        st = (ctypes.c_uint32 * 16)()
-        hip = ctypes.CDLL("libamdhip64.so.7")
-        torch.cuda.synchronize(self.device)
-        hip.hipMemcpy(st, ctypes.c_void_p(self._state), 64, 2)                  # hipMemcpyDeviceToHost
-        return int(st[2])
+        calls, failed = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self._lib.nvh_allreduce_status(self._state, ctypes.byref(calls), ctypes.byref(failed)), "nvh_allreduce_status")
+        return int(failed.value)
 
 
 _comm = None          # process-wide choice, made once by init_tensor_parallel_comm
