@@ -24,7 +24,7 @@ struct DecodeArgs {
     float scale_log2;            // softmax scale * log2(e)
     int out_f32;
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
-    // chunked kernel (default): partial records [B*KVH][chunks][G*(D+2)] fp32 alias ws_acc; arrival tickets per (b, kv head)
+    // chunked kernel (default): partial records [B*KVH][chunks][G rows of (D + 4) floats: O, max, sum, 0, 0; padded to 256 B] fp32 alias ws_acc; arrival tickets per (b, kv head)
     unsigned* counters;          // [B*KVH], zero before the launch, left zero by it
     int chunks;                  // workgroups per (sequence, kv head); passes are dealt to them round-robin
     uint16_t* out_packed;        // nullable: bf16 output also in MFMA-fragment order [ceil(B/16)][H*D/32][64][8] (pack_index)

@@ -351,6 +351,26 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
 #define NVH_HANDOFF_ACQUIRE() do {} while (0)
 #endif
 
+// 16-byte forms of the same two accesses for the chunk records (buffer_store_dwordx4 / buffer_load_dwordx4 with sc1 through a raw
+// buffer descriptor of the (sequence, kv head)'s record group: the compiler sees them as memory operations and counts their vmcnt,
+// which inline-asm global_* accesses would leave to hand-placed waits).  Byte offsets; out-of-range accesses cannot happen (the
+// descriptor spans exactly the group).
+#ifdef NVH_HANDOFF_FENCES
+constexpr int kRecAux = 0;
+#else
+constexpr int kRecAux = 16;                               // gfx940+ cache-policy bits of the buffer intrinsics: 1 = sc0, 2 = nt, 16 = sc1
+#endif
+typedef __amdgpu_buffer_rsrc_t RecBuf;
+__device__ __forceinline__ RecBuf rec_buffer(float* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);     // raw buffer, 32-bit data format word of gfx9
+}
+__device__ __forceinline__ void st16_sc1(RecBuf rb, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rb, (int)byte_off, 0, kRecAux);
+}
+__device__ __forceinline__ f32x4 ld16_sc1(RecBuf rb, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (int)byte_off, 0, kRecAux));
+}
+
 template <int D>
 __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const DecodeArgs a, const int G) {
     using geo = MGeo<D>;
@@ -828,34 +848,43 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     __syncthreads();
 
     // ---- merge the live waves (those with a live tile in the workgroup's first pass), then the live chunks
+    // A thread owns ITEMS of four consecutive dims of one head (16 bytes): the LDS reads, the record stores and loads of the
+    // hand-off and the output stores are all 16-byte accesses (a write-through store is one fabric write per LANE whatever its
+    // width: a record of G*D floats is G*D/4 writes instead of G*D)
     const int n_waves = min(WAVES, (ctx - split * SPLIT + WT - 1) / WT);
     const int live_chunks = min(NC, live_passes);
-    constexpr int EPT = 16 * D / (MW * 64);                   // elements per thread when G == 16
-    float Mv[EPT], Lv[EPT], Ov[EPT];
+    constexpr int IPT = (16 * D / 4 + MW * 64 - 1) / (MW * 64);   // items per thread when G == 16
+    constexpr int DSH = D == 64 ? 6 : 7;
+    const int n_items = G * (D / 4);
+    float Mv[IPT], Lv[IPT];
+    f32x4 Ov[IPT];
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = tid + e * WAVES * 64;
-        Mv[e] = -INFINITY; Lv[e] = 0.f; Ov[e] = 0.f;
-        if (idx < G * D) {
-            const int g = idx / D;
+    for (int e = 0; e < IPT; ++e) {
+        const int it = tid + e * WAVES * 64;
+        Mv[e] = -INFINITY; Lv[e] = 0.f; Ov[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (it < n_items) {
+            const int g = (4 * it) >> DSH;
             // every wave's (max, sum, O) requested at once (dead waves re-read the last live one and are masked): one LDS
             // latency instead of one per wave
-            float mw[WAVES], lw[WAVES], ow[WAVES];
+            float mw[WAVES], lw[WAVES];
+            f32x4 ow[WAVES];
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) {
                 const int wc = w < n_waves ? w : n_waves - 1;
                 mw[w] = lds_ml[(wc * 2 + 0) * 16 + g];
                 lw[w] = lds_ml[(wc * 2 + 1) * 16 + g];
-                ow[w] = reinterpret_cast<const float*>(lds + wc * WAVE_LDS)[idx];
+                ow[w] = reinterpret_cast<const f32x4*>(lds + wc * WAVE_LDS)[it];
             }
             float M = mw[0];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) M = fmaxf(M, mw[w]);      // (a repeated wave does not change the max)
-            float ov = 0.f, L = 0.f;
+            f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f};
+            float L = 0.f;
 #pragma unroll
             for (int w = 0; w < WAVES; ++w) {
                 const float f = w < n_waves ? fast_exp2(mw[w] - M) : 0.f;
-                ov = fmaf(ow[w], f, ov);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ov[j] = fmaf(ow[w][j], f, ov[j]);
                 L = fmaf(lw[w], f, L);
             }
             Mv[e] = M; Lv[e] = L; Ov[e] = ov;
@@ -863,20 +892,19 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     }
     NVH_TSTAMP(1);
     if (live_chunks > 1) {
-        // floats per record: O[G][D], max[G], sum[G], padded so that every record starts on a 256-byte boundary (a wave's store
-        // instruction is 256 contiguous bytes: whole lines, none shared with another workgroup's record)
-        const int rec = (G * (D + 2) + NVH_REC_ALIGN - 1) / NVH_REC_ALIGN * NVH_REC_ALIGN;
+        // record: G rows of [D floats of O | max | sum | 0 | 0], padded so that every record starts on a 256-byte boundary (no
+        // line shared with another workgroup's record); byte offsets inside the (sequence, kv head)'s record group
+        const int rec = (G * (D + 4) + NVH_REC_ALIGN - 1) / NVH_REC_ALIGN * NVH_REC_ALIGN;
         float* const recs = e_ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
-        float* const mine = recs + (int64_t)split * rec;
+        const RecBuf rb = rec_buffer(recs, (uint32_t)(NC * rec * 4));
+        const uint32_t mine = (uint32_t)(split * rec * 4);
 #pragma unroll
-        for (int e = 0; e < EPT; ++e) {
-            const int idx = tid + e * WAVES * 64;
-            if (idx < G * D) {
-                st_sc1(mine + idx, Ov[e]);
-                if (idx % D == 0) {
-                    st_sc1(mine + G * D + idx / D, Mv[e]);
-                    st_sc1(mine + G * D + G + idx / D, Lv[e]);
-                }
+        for (int e = 0; e < IPT; ++e) {
+            const int it = tid + e * WAVES * 64;
+            if (it < n_items) {
+                const int g = (4 * it) >> DSH;
+                st16_sc1(rb, mine + 16 * (it + g), Ov[e]);                        // row g starts at float g * (D + 4)
+                if (((4 * it) & (D - 1)) == 0) st16_sc1(rb, mine + 4 * (g * (D + 4) + D), f32x4{Mv[e], Lv[e], 0.f, 0.f});
             }
         }
         NVH_TSTAMP(2);
@@ -899,38 +927,40 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         NVH_TSTAMP(4);
         if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
         // records are requested CB at a time (every load of a batch in flight together); four chunks, the common shape of a
-        // full launch, are one batch of 12 loads per thread rather than an 8-wide batch with half of it repeated
+        // full launch, are one batch of 8 loads per thread rather than an 8-wide batch with half of it repeated
         auto merge_chunks = [&](auto cb_tag) {
             constexpr int CB = decltype(cb_tag)::value;
 #pragma unroll
-            for (int e = 0; e < EPT; ++e) {
-                const int idx = tid + e * WAVES * 64;
-                if (idx < G * D) {
-                    const int g = idx / D;
-                    float M = -INFINITY, ov = 0.f, L = 0.f;
+            for (int e = 0; e < IPT; ++e) {
+                const int it = tid + e * WAVES * 64;
+                if (it < n_items) {
+                    const int g = (4 * it) >> DSH;
+                    float M = -INFINITY, L = 0.f;
+                    f32x4 ov = f32x4{0.f, 0.f, 0.f, 0.f};
                     for (int c0 = 0; c0 < live_chunks; c0 += CB) {
-                        float mv[CB], lv[CB], av[CB];
+                        f32x4 ml[CB], av[CB];
 #pragma unroll
                         for (int i = 0; i < CB; ++i) {
                             const int c = c0 + i < live_chunks ? c0 + i : live_chunks - 1;
-                            const float* r = recs + (int64_t)c * rec;
-                            mv[i] = ld_sc1(r + G * D + g);
-                            lv[i] = ld_sc1(r + G * D + G + g);
-                            av[i] = ld_sc1(r + idx);
+                            const uint32_t r = (uint32_t)(c * rec * 4);
+                            ml[i] = ld16_sc1(rb, r + 4 * (g * (D + 4) + D));
+                            av[i] = ld16_sc1(rb, r + 16 * (it + g));
                         }
                         float Mc = M;
 #pragma unroll
                         for (int i = 0; i < CB; ++i)
-                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, mv[i]);
+                            if (c0 + i < live_chunks) Mc = fmaxf(Mc, ml[i][0]);
                         const float fo = fast_exp2(M - Mc);        // M = -inf on the first group -> 0
-                        ov *= fo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ov[j] *= fo;
                         L *= fo;
 #pragma unroll
                         for (int i = 0; i < CB; ++i)
                             if (c0 + i < live_chunks) {
-                                const float f = fast_exp2(mv[i] - Mc);
-                                ov = fmaf(av[i], f, ov);
-                                L = fmaf(lv[i], f, L);
+                                const float f = fast_exp2(ml[i][0] - Mc);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) ov[j] = fmaf(av[i][j], f, ov[j]);
+                                L = fmaf(ml[i][1], f, L);
                             }
                         M = Mc;
                     }
@@ -943,14 +973,19 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         NVH_TSTAMP(5);
     }
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int idx = tid + e * WAVES * 64;
-        if (idx < G * D) {
-            const float r = Ov[e] / Lv[e];
-            const int64_t oidx = ((int64_t)b * e_h + kh * G) * D + idx;
-            if (e_out_f32) reinterpret_cast<float*>(e_out)[oidx] = r;
-            else reinterpret_cast<__bf16*>(e_out)[oidx] = (__bf16)r;
-            if (e_out_packed) e_out_packed[pack_index(b, kh * G * D + idx, e_h * D)] = __builtin_bit_cast(uint16_t, (__bf16)r);
+    for (int e = 0; e < IPT; ++e) {
+        const int it = tid + e * WAVES * 64;
+        if (it < n_items) {
+            f32x4 r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = Ov[e][j] / Lv[e];
+            const int64_t oidx = ((int64_t)b * e_h + kh * G) * D + 4 * it;
+            bf16x4 rb16;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rb16[j] = (__bf16)r[j];
+            if (e_out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(e_out) + oidx) = r;
+            else *reinterpret_cast<bf16x4*>(reinterpret_cast<uint16_t*>(e_out) + oidx) = rb16;
+            if (e_out_packed) *reinterpret_cast<bf16x4*>(e_out_packed + pack_index(b, kh * G * D + 4 * it, e_h * D)) = rb16;
         }
     }
     NVH_STAMP(7);
