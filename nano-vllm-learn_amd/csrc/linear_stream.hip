@@ -349,12 +349,13 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             __syncthreads();
             if (tid == 0) {
                 const unsigned old = __hip_atomic_fetch_add(&e_counters[tile * kTicketWords], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (old == (unsigned)p_ksplit - 1)
-                    __hip_atomic_store(&e_counters[tile * kTicketWords], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero again for the next launch
                 *lds_ticket = old;
             }
             __syncthreads();
             if (*lds_ticket != (unsigned)p_ksplit - 1) return;       // workgroup-uniform; MULTI never splits K
+            // zero the ticket for the next launch: behind the barrier (whose wait would otherwise hold the workgroup until the store
+            // is acknowledged), so that it completes under the partial loads
+            if (tid == 0) __hip_atomic_store(&e_counters[tile * kTicketWords], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const float* const base = e_ws + (int64_t)tile * p_ksplit * PSTRIDE;
             // partials are requested SB splits at a time, all loads of a batch in flight together; up to four splits (the
             // balanced down_proj shape) are one batch instead of an 8-wide one with half of it repeated

@@ -918,7 +918,6 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             // dense tickets the 16-32 pairs that share a line made every pair's last arriver queue behind all their adds
             unsigned* const ctr = e_counters + ((int64_t)b * p_kvh + kh) * kTicketStride;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == (unsigned)live_chunks - 1) __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *lds_ticket = old;
             NVH_HANDOFF_ACQUIRE();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -926,6 +925,11 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         __syncthreads();
         NVH_TSTAMP(4);
         if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
+        // the last arriver zeroes the ticket for the next launch.  Issued here, behind the barrier, and not next to the add: the
+        // barrier's wait would hold the whole workgroup until this store is acknowledged (~0.2 us on the launch's critical path);
+        // now it completes under the record loads (the kernel's end waits for it like for the output stores)
+        if (tid == 0)
+            __hip_atomic_store(e_counters + ((int64_t)b * p_kvh + kh) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // records are requested CB at a time (every load of a batch in flight together); four chunks, the common shape of a
         // full launch, are one batch of 8 loads per thread rather than an 8-wide batch with half of it repeated
         auto merge_chunks = [&](auto cb_tag) {

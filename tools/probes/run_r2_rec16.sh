@@ -1,5 +1,5 @@
 #!/bin/bash
-# 16-byte record accesses in the decode hand-off: parity, then same-box A/B against the build before the change (tools/probes/ab/base.so)
+# 16-byte record accesses in the decode hand-off: parity, then same-box A/B against the build before the change (${BASE:-tools/probes/ab/base.so})
 set -o pipefail
 mkdir -p gpurun_out/rec16
 timeout -k 10 700 python -m pytest tests/test_hip_parity.py tests/test_hip_model_vs_oracle.py tests/test_hip_layer_ops.py -m gpu -x -q -k "decode or handoff or config3 or config4 or attention_module or model or engine or fused_decode" > gpurun_out/rec16/pytest.log 2>&1
@@ -9,7 +9,7 @@ tail -5 gpurun_out/rec16/pytest.log
 rm -f gpurun_out/rec16/micro.log
 mb() { timeout -k 10 120 python tools/microbench.py decode --graph "$@" >> gpurun_out/rec16/micro.log 2>&1 || exit 1; }
 for rep in 1 2; do
-for lib in "" tools/probes/ab/base.so; do
+for lib in "" "${BASE:-tools/probes/ab/base.so}"; do
   export NVH_LIB_PATH=$lib
   [ -z "$lib" ] && unset NVH_LIB_PATH
   echo "# lib ${lib:-new} rep $rep" >> gpurun_out/rec16/micro.log

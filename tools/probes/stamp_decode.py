@@ -38,7 +38,7 @@ def main():
     lib.nvh_paged_decode_workspace.restype = ctypes.c_size_t
     lib.nvh_paged_decode_workspace.argtypes = [ctypes.c_int] * 5
     ws = torch.zeros(lib.nvh_paged_decode_workspace(b, h, d, nblk, bs), dtype=torch.uint8, device="cuda")   # ticket header + chunk records
-    waves = 8 if d == 64 else 4                                       # waves per workgroup of the chunked kernel
+    waves = 8                                                         # waves per workgroup of the chunked kernel (both head dims)
     stamps = torch.zeros(b * kvh * nsplit * waves * 8, dtype=torch.int64, device="cuda")
     lib.nvh_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr()))
     lib.nvh_paged_decode.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_int] * 6 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
