@@ -980,9 +980,12 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     for (int e = 0; e < IPT; ++e) {
         const int it = tid + e * WAVES * 64;
         if (it < n_items) {
+            // one reciprocal per item (a correctly rounded 1 / sum, then a product per dim: <= 1.5 ulp of fp32, far inside the bf16
+            // output's rounding) instead of four IEEE divisions in a row at the very end of the launch's critical path
+            const float inv_l = 1.f / Lv[e];
             f32x4 r;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = Ov[e][j] / Lv[e];
+            for (int j = 0; j < 4; ++j) r[j] = Ov[e][j] * inv_l;
             const int64_t oidx = ((int64_t)b * e_h + kh * G) * D + 4 * it;
             bf16x4 rb16;
 #pragma unroll
