@@ -668,6 +668,21 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     void* const e_out = a.out;
     uint16_t* const e_out_packed = a.out_packed;
     const int e_out_f32 = a.out_f32, e_h = a.h;
+    // scalars of the tail (record group, ticket, output row), computed under the first K/V images as well: ~40 scalar instructions
+    // (64-bit multiplies) that otherwise sit between the LDS merge and the record stores, on every workgroup's way to its ticket
+    // (offsets, not pointers, go through the pin: a pointer that has passed an asm statement has lost its address space and its
+    // accesses become flat_ instructions)
+    int t_rec;
+    int64_t t_recs_off, t_ctr_off, t_orow;
+    auto tail_scalars = [&]() {
+        // floats per record: G rows of [D floats of O | max | sum | 0 | 0], padded so that every record starts on a 256-byte boundary
+        t_rec = (G * (D + 4) + NVH_REC_ALIGN - 1) / NVH_REC_ALIGN * NVH_REC_ALIGN;
+        const int64_t pair = (int64_t)b * p_kvh + kh;
+        t_recs_off = pair * NC * t_rec;
+        t_ctr_off = pair * kTicketStride;
+        t_orow = ((int64_t)b * e_h + kh * G) * D;
+        asm volatile("" : "+s"(t_recs_off), "+s"(t_ctr_off), "+s"(t_rec), "+s"(t_orow));
+    };
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
         // first K image, then q, then the first V image: everything the K DMA needs arrived with the wave (preloaded arguments,
         // the block id), while q's pointer is still behind a kernarg load; the first wait below (q and K landed) counts on q
@@ -686,6 +701,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         issue_kv(tok0, bid, 0, 2);
         NVH_STAMP(2);
         asm volatile("" ::"s"(e_ws_acc), "s"(e_counters), "s"(e_out), "s"(e_out_packed), "s"(e_out_f32), "s"(e_h));
+        tail_scalars();
         bf16x8 qf[STEPS];
         for (int buf = 0;; buf ^= 1) {
             const int tok_next = tok0 + NC * SPLIT;
@@ -844,6 +860,8 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
                 lds_ml[(wave * 2 + 1) * 16 + lq] = l_run;
             }
         }
+    } else {
+        tail_scalars();
     }
     __syncthreads();
 
@@ -894,8 +912,8 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     if (live_chunks > 1) {
         // record: G rows of [D floats of O | max | sum | 0 | 0], padded so that every record starts on a 256-byte boundary (no
         // line shared with another workgroup's record); byte offsets inside the (sequence, kv head)'s record group
-        const int rec = (G * (D + 4) + NVH_REC_ALIGN - 1) / NVH_REC_ALIGN * NVH_REC_ALIGN;
-        float* const recs = e_ws_acc + ((int64_t)b * p_kvh + kh) * NC * rec;
+        const int rec = t_rec;
+        float* const recs = e_ws_acc + t_recs_off;
         const RecBuf rb = rec_buffer(recs, (uint32_t)(NC * rec * 4));
         const uint32_t mine = (uint32_t)(split * rec * 4);
 #pragma unroll
@@ -916,7 +934,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // one ticket per 128-byte line: the memory side executes the adds on one line one after the other (~12 ns each); with
             // dense tickets the 16-32 pairs that share a line made every pair's last arriver queue behind all their adds
-            unsigned* const ctr = e_counters + ((int64_t)b * p_kvh + kh) * kTicketStride;
+            unsigned* const ctr = e_counters + t_ctr_off;
             const unsigned old = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *lds_ticket = old;
             NVH_HANDOFF_ACQUIRE();
@@ -929,7 +947,7 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
         // barrier's wait would hold the whole workgroup until this store is acknowledged (~0.2 us on the launch's critical path);
         // now it completes under the record loads (the kernel's end waits for it like for the output stores)
         if (tid == 0)
-            __hip_atomic_store(e_counters + ((int64_t)b * p_kvh + kh) * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(e_counters + t_ctr_off, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // records are requested CB at a time (every load of a batch in flight together); four chunks, the common shape of a
         // full launch, are one batch of 8 loads per thread rather than an 8-wide batch with half of it repeated
         auto merge_chunks = [&](auto cb_tag) {
@@ -980,13 +998,13 @@ __global__ __launch_bounds__(NW * 64) void paged_decode_chunked_kernel(
     for (int e = 0; e < IPT; ++e) {
         const int it = tid + e * WAVES * 64;
         if (it < n_items) {
-            // one reciprocal per item (a correctly rounded 1 / sum, then a product per dim: <= 1.5 ulp of fp32, far inside the bf16
-            // output's rounding) instead of four IEEE divisions in a row at the very end of the launch's critical path
-            const float inv_l = 1.f / Lv[e];
+            // one reciprocal per item (v_rcp_f32: 1 ulp; then a product per dim: <= 2 ulp of fp32, far inside the bf16 output's rounding
+            // and the 1e-3 bar of the fp32 output) instead of four IEEE divisions in a row at the very end of the launch's critical path
+            const float inv_l = __builtin_amdgcn_rcpf(Lv[e]);
             f32x4 r;
 #pragma unroll
             for (int j = 0; j < 4; ++j) r[j] = Ov[e][j] * inv_l;
-            const int64_t oidx = ((int64_t)b * e_h + kh * G) * D + 4 * it;
+            const int64_t oidx = t_orow + 4 * it;
             bf16x4 rb16;
 #pragma unroll
             for (int j = 0; j < 4; ++j) rb16[j] = (__bf16)r[j];
