@@ -99,7 +99,7 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
  * The same call through a chosen formulation of the decode kernel (tests and A/B measurements; nvh_paged_decode always runs
  * NVH_DECODE_CHUNKED with waves = chunks = 0).  All variants compute the same function and are held to the same parity bar:
  *   NVH_DECODE_CHUNKED     one launch: MFMA tiles over the GQA group, split-KV passes dealt to `chunks` workgroups per
- *                          (sequence, kv head), last-arriver combine.  waves: 0 / 8 = eight waves per workgroup at hd 64, 4 = four.
+ *                          (sequence, kv head), last-arriver combine.  waves per workgroup: 4 or 8; 0 = the default (8 at hd 64, 4 at hd 128).
  *                          chunks: 0 = one wave of workgroups over the device's CUs, > 0 = that many (clamped to the passes).
  *   NVH_DECODE_CHUNKED_P128  the chunked kernel with 128-token passes at hd 64 (16-token wave tiles; hd 128 already works that way)
  *   NVH_DECODE_SPLIT_MFMA  the single-pass MFMA split kernel + a combine launch (flash-decoding in two launches).

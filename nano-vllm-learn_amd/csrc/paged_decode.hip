@@ -38,7 +38,9 @@
 #include "kernels.h"
 
 #ifndef NVH_D128_WAVES
-#define NVH_D128_WAVES 8     // waves per workgroup of the chunked kernel at head_dim 128 when the caller does not choose (4 or 8)
+#define NVH_D128_WAVES 4     // waves per workgroup of the chunked kernel at head_dim 128 when the caller does not choose (4 or 8).
+                             // With 4-byte records 8 waves won (7/1/128 ctx 1536: 11.1 vs 12.1 us); since the records move as 16-byte items
+                             // 4 waves (32-token tiles, the k = 32 MFMA) win everywhere: 7/1/128 9.2 vs 9.6, 28/4/128 19.8 vs 20.6, 16/8/128 33.3 vs 34.0
 #endif
 
 namespace nvh {
@@ -1092,8 +1094,8 @@ int launch_valu_d(const DecodeArgs& a, int g, hipStream_t stream) {
 
 template <int D>
 int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
-    // 8 waves (two per SIMD; 32-token tiles at D = 64, 16-token tiles at D = 128) by default: measured 8.5 % faster than 4 waves at
-    // D = 64 (ctx 1536: 11.0 -> 10.05 us per call); a.waves = 4 (nvh_paged_decode_variant) selects the one-wave-per-SIMD shape.
+    // D = 64: 8 waves (two per SIMD; 32-token tiles) by default: 6.97 vs 7.44 us at ctx 1034, 8.36 vs 8.47 at 1536; D = 128: NVH_D128_WAVES;
+    // a.waves = 4 / 8 (nvh_paged_decode_variant) selects either shape.
     const int waves = a.waves == 4 ? 4 : (a.waves == 8 ? 8 : (D == 64 ? 8 : NVH_D128_WAVES));
     dim3 grid(a.kvh, a.batch, a.chunks);
     const int bs_shift = (a.block_size & (a.block_size - 1)) == 0 ? __builtin_ctz(a.block_size) : -1;
