@@ -662,13 +662,14 @@ def test_prefill_short_sequence_kernel(seed):
 @pytest.mark.gpu
 @pytest.mark.parametrize("H,KVH,D,background", [(7, 1, 64, False), (7, 1, 64, True), (16, 1, 128, False), (4, 2, 128, True)])
 def test_chunk_handoff_extreme_geometry_under_graph_replay(H, KVH, D, background):
-    """The chunk hand-off (tagged granules, merger = chunk 0, generation advanced per launch) where it is widest: one or two
-    (sequence, kv head) pairs split over the most chunks the launch allows (16 at D = 64: four record batches per element), the
-    SAME captured launch replayed 320 times on the SAME workspace with a different query and a different context length every
-    time — so a record slot holds, at every replay, valid-looking granules of an EARLIER launch (other values, an older tag) —
-    and every replay compared with the oracle's answer for that (query, context).  Contexts cycle through 16, 9, 2 and 1 live
-    chunks, a ragged last pass, and 0 (padding row: no hand-off, zeros).  `background`: a second stream keeps the memory
-    system busy with copies meanwhile (uneven load: granules land late and out of order relative to the merger's sweeps)."""
+    """The chunk hand-off (write-through 16-byte record items, drained, one arrival ticket per pair, the last arriver merges)
+    where it is widest: one or two (sequence, kv head) pairs split over the most chunks the launch allows (16 at D = 64: two record
+    batches per item), the SAME captured launch replayed 320 times on the SAME workspace with a different query and a different
+    context length every time — so a record slot holds, at every replay, the valid-looking record of an EARLIER launch, and the
+    ticket must have been returned to zero by the previous replay's last arriver — and every replay compared with the oracle's
+    answer for that (query, context).  Contexts cycle through 16, 9, 2 and 1 live chunks, a ragged last pass, and 0 (padding row:
+    no hand-off, zeros).  G = 16 at D = 128 takes the two-items-per-thread path of the 4-wave shape.  `background`: a second
+    stream keeps the memory system busy with copies meanwhile (uneven load: records land late relative to the tickets)."""
     from nanovllm_hip import ops
     B, bs, width = 2 if KVH == 2 else 1, 256, 16
     split = 256 if D == 64 else 128
@@ -712,7 +713,7 @@ def test_chunk_handoff_extreme_geometry_under_graph_replay(H, KVH, D, background
         outs[n].copy_(out_s)
     torch.cuda.synchronize()
     got = outs.cpu().numpy()
-    assert np.isfinite(got).all(), "a merger gave up on its sweep (NaN marks a bounded-spin timeout)"
+    assert np.isfinite(got).all()
     worst = 0.0
     for n, ci in enumerate(order):
         err = np.abs(got[n] - cases[ci][2]).max()
