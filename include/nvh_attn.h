@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NVH_VERSION 200          /* major*100 + minor */
+#define NVH_VERSION 201          /* major*100 + minor; 201: nvh_allreduce_status, decode records as 16-byte items (same workspace size) */
 
 /* dtype codes */
 #define NVH_BF16 0
