@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NVH_VERSION 201          /* major*100 + minor; 201: nvh_allreduce_status, decode records as 16-byte items (same workspace size) */
+#define NVH_VERSION 202          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch */
 
 /* dtype codes */
 #define NVH_BF16 0
@@ -286,6 +286,13 @@ typedef struct nvh_linear_desc {
     float* candidate_val;
     int32_t* candidate_idx;
     int64_t candidate_stride;
+    /* prefetch hint (streaming form, optional): device memory the NEXT launches on this stream will stream once — typically the
+       weights of the following projection.  A decode-sized projection occupies 36-224 of the device's CUs; the workgroups this
+       launch adds for the idle ones read the range (default cache policy) and drop it, so that the later launch finds its operand
+       in the caches.  Pure hint: results do not depend on it, only whole lines inside [prefetch, prefetch + prefetch_bytes) are
+       read, NULL / 0 = none. */
+    const void* prefetch;
+    size_t prefetch_bytes;
 } nvh_linear_desc;
 int nvh_linear_small_m_ex(const nvh_linear_desc* desc, int dtype, void* stream);
 /* residual[n_rows, hidden] += y (bf16, one rounding — the add of add_rms_forward, layers/layernorm.py:35-36) and, if `packed` is

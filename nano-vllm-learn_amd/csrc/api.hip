@@ -441,6 +441,12 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     a.x_packed = d->x_packed; a.out_packed = (uint16_t*)d->out_packed; a.ws_raw = d->workspace; a.ws_bytes = d->workspace_bytes;
     a.ws = nullptr; a.counters = nullptr; a.ksplit = 1; a.tiles = 0;
     a.cand_val = d->candidate_val; a.cand_idx = d->candidate_idx; a.cand_stride = d->candidate_stride;
+    // prefetch hint: whole 128-byte lines inside [prefetch, prefetch + prefetch_bytes) only (reads never leave the caller's range)
+    a.pf_ptr = nullptr; a.pf_bytes = 0;
+    if (d->prefetch && d->prefetch_bytes >= 256) {
+        const uintptr_t p0 = ((uintptr_t)d->prefetch + 127) & ~(uintptr_t)127, p1 = ((uintptr_t)d->prefetch + d->prefetch_bytes) & ~(uintptr_t)127;
+        if (p1 > p0) { a.pf_ptr = (const void*)p0; a.pf_bytes = (int64_t)(p1 - p0); }
+    }
     const int rc = launch_linear_stream(a, (hipStream_t)stream);
     if (rc != -100) return rc;
     if (d->x_packed || d->out_packed || d->candidate_val) {

@@ -116,6 +116,8 @@ struct LinearArgs {
     float* cand_val;             // NONE only, nullable: greedy candidates instead of (or besides) the outputs: every workgroup
     int32_t* cand_idx;           // writes, per row, the largest bf16 output of its columns and that column's index:
     int64_t cand_stride;         // cand_*[workgroup * cand_stride + row]; ties -> lowest column (lm_head + argmax in one pass)
+    const void* pf_ptr;          // nullable: bytes a LATER launch will stream (its weights): the CUs this launch leaves idle read them
+    int64_t pf_bytes;            // once (default cache policy), so that the later launch finds them in the memory-side cache
 };
 int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
 int launch_linear_stream(const LinearArgs& a, hipStream_t stream);   // linear_stream.hip; returns -100 when the shape is not its own

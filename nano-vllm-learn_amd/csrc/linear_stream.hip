@@ -71,6 +71,16 @@ __device__ __forceinline__ float ld_sc1(const float* p) {
     return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// compute units of the current device (256 on MI355X), read once
+static int device_cus_ls() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -85,6 +95,30 @@ __device__ __forceinline__ void wait_all_but_pieces(int np) {
         case 4: wait_vm<4 * PER>(); break;
         default: wait_vm<5 * PER>(); break;
     }
+}
+
+// Prefetch role (workgroups with blockIdx.x >= tiles, on CUs the launch would leave idle): touch one dword of every NVH_PF_STRIDE bytes
+// of this workgroup's share of [base, base + bytes) with default-policy loads and drop the data.
+#ifndef NVH_PF_STRIDE
+#define NVH_PF_STRIDE 32
+#endif
+__device__ __forceinline__ void prefetch_lines(const void* base, int64_t bytes, int idx, int n, int tid, int nthreads) {
+    constexpr int SH = NVH_PF_STRIDE == 32 ? 5 : (NVH_PF_STRIDE == 64 ? 6 : 7);
+    const int64_t lines = bytes >> SH;
+    const int64_t per = (lines + n - 1) / n;
+    const int64_t l0 = idx * per, l1 = l0 + per < lines ? l0 + per : lines;
+    const unsigned char* const b = reinterpret_cast<const unsigned char*>(base);
+    for (int64_t l = l0 + tid; l < l1; l += 8 * nthreads) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t ll = l + (int64_t)u * nthreads;
+            if (ll < l1) {
+                unsigned sink;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(b + (ll << SH)) : "memory");
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // PM = most pieces one wave may own (4; 5 where it lets a split-K launch fit the 256 CUs with equal workgroups)
@@ -119,6 +153,13 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lq = lane & 15, lg = lane >> 4;
+    if constexpr (!MULTI) {
+        if ((int)blockIdx.x >= p_tiles) {                        // workgroup-uniform: this workgroup only prefetches (launcher: pf_ptr set)
+            prefetch_lines(a.pf_ptr, a.pf_bytes, (int)(blockIdx.y * (gridDim.x - p_tiles) + (blockIdx.x - p_tiles)),
+                           (int)((gridDim.x - p_tiles) * gridDim.y), tid, TPB);
+            return;
+        }
+    }
     LS_STAMP(0);
 
     // ---- this wave's K range: the tile's pieces are split over the ksplit workgroups, then over the 4 waves
@@ -497,6 +538,16 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     LS_STAMP(6);
 }
 
+// grid of a single-tile-per-workgroup launch: (tiles, ksplit), widened in x by prefetch workgroups for the CUs it leaves idle
+static dim3 grid_of(const LinearArgs& a) {
+    int extra = 0;
+    if (a.pf_ptr && a.pf_bytes >= 128) {
+        const int spare = device_cus_ls() - a.tiles * a.ksplit;
+        if (spare >= 8) extra = spare / a.ksplit;
+    }
+    return dim3(a.tiles + extra, a.ksplit);
+}
+
 template <int MT, int EPI, int NORM, bool XPACK>
 int launch_x(const LinearArgs& a_in, hipStream_t stream) {
     LinearArgs a = a_in;
@@ -512,7 +563,7 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         const int wide_tiles = (a.inter + 23) / 24;                  // 24 + 24 columns per workgroup
         if (a.ksplit == 1 && a.tiles > 256 && wide_tiles <= 256 && a.inter % 8 == 0) {
             a.tiles = wide_tiles;
-            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, true, 8>), dim3(a.tiles, 1), dim3(8 * 64), 0, stream, LS_FLAT(a));
+            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, true, 8>), grid_of(a), dim3(8 * 64), 0, stream, LS_FLAT(a));
             return check_launch("linear_stream");
         }
     }
@@ -523,7 +574,7 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
         const int pieces = a.K / 64, ks5 = (pieces + SW * 5 - 1) / (SW * 5);
         if (a.ksplit > 1 && a.tiles * a.ksplit > 256 && a.tiles * ks5 <= 256) {
             a.ksplit = ks5;
-            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 3, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, LS_FLAT(a));
+            hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 3, false, 8>), grid_of(a), dim3(8 * 64), 0, stream, LS_FLAT(a));
             return check_launch("linear_stream");
         }
     }
@@ -531,10 +582,10 @@ int launch_x(const LinearArgs& a_in, hipStream_t stream) {
     // (an LM head too deep for the multi-tile form, e.g. K = 3584: tens of thousands of workgroups, where four waves with four
     // pieces each measured 262 us against 326 us for eight with two)
     if (!(EPI == EPI_NONE && a.tiles > 1024)) {
-        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, false, 8>), dim3(a.tiles, a.ksplit), dim3(8 * 64), 0, stream, LS_FLAT(a));
+        hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false, 2, false, 8>), grid_of(a), dim3(8 * 64), 0, stream, LS_FLAT(a));
         return check_launch("linear_stream");
     }
-    hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), dim3(a.tiles, a.ksplit), dim3(SW * 64), 0, stream, LS_FLAT(a));
+    hipLaunchKernelGGL((linear_stream_kernel<MT, EPI, NORM, XPACK, false>), grid_of(a), dim3(SW * 64), 0, stream, LS_FLAT(a));
     return check_launch("linear_stream");
 }
 

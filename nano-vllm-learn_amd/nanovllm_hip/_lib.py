@@ -26,7 +26,8 @@ class LinearDesc(ctypes.Structure):
                 ("slot_mapping", ctypes.c_void_p), ("h", ctypes.c_int32), ("kvh", ctypes.c_int32), ("hd", ctypes.c_int32),
                 ("norm_folded", ctypes.c_int32), ("x_packed", ctypes.c_int32), ("out_packed", ctypes.c_void_p),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_size_t),
-                ("candidate_val", ctypes.c_void_p), ("candidate_idx", ctypes.c_void_p), ("candidate_stride", ctypes.c_int64)]
+                ("candidate_val", ctypes.c_void_p), ("candidate_idx", ctypes.c_void_p), ("candidate_stride", ctypes.c_int64),
+                ("prefetch", ctypes.c_void_p), ("prefetch_bytes", ctypes.c_size_t)]
 
 
 EPI_NONE, EPI_SILU_MUL, EPI_RESIDUAL_ADD, EPI_ROPE_STORE = 0, 1, 2, 3

@@ -276,6 +276,7 @@ class QwenDecoderLayer(nn.Module):
 
 
 FUSED_DECODE = True          # tests flip this to compare the fused decode layer with the plain one
+PREFETCH_WEIGHTS = True      # qkv / down launches pull the NEXT small projection's weights into the caches on their idle CUs (A/B runs flip it)
 
 
 class PackedResidual:
@@ -388,8 +389,17 @@ class QwenForCausalLM(nn.Module):
         b = self._decode_buffers(m, residual.device)
         resid_p, act_p, attn_p, ws, ybuf = b["resid_p"], b["act_p"], b["attn_p"], b["ws"], b["y"]
         tp = _tp()[1]
+        # weight prefetch (nvh_linear_desc.prefetch): the qkv launch runs 36 workgroups and the o_proj launch 56 on 256 CUs, each
+        # pulling 28-57 KB of weights whose first-byte latency is most of the launch.  The launch right before each of them (down of the
+        # previous layer, qkv) lends its idle CUs to read those weights first: -3.3 % on the decode step.  The same for the two large
+        # projections does not pay (gate_up's 17 MB in the o_proj launch: +1.3 %; down's in the gate_up launch: 0), nor does a
+        # prefetch two launches ahead
+        nxt = list(self.layers)[1:] + [None]
         for i, layer in enumerate(self.layers):
             a, mlp = layer.self_attn, layer.mlp
+            pf_in_qkv = a.o_proj.weight if PREFETCH_WEIGHTS else None
+            pf_in_dn = fw["qkv"][i + 1] if PREFETCH_WEIGHTS and nxt[i] is not None else None
+            pf_in_o = pf_in_gu = None
             if i == 0:                                                    # layer 0 reads the embedding rows as they are, or packed
                 x, xrows = (residual, None) if packed0 is None else (packed0, m)
             else:
@@ -398,20 +408,20 @@ class QwenForCausalLM(nn.Module):
                 # Qwen3: the per-head q/k RMSNorm needs a whole head in one workgroup, so it cannot ride in the GEMM epilogue:
                 # plain projection, then (q/k-norm -> RoPE -> KV store) as the one nvh_rope_store launch (qwen3.py:108-116)
                 qkv = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
-                                       norm_eps=layer.input_layernorm.eps, epilogue="none", workspace=ws)
+                                       norm_eps=layer.input_layernorm.eps, epilogue="none", workspace=ws, prefetch=pf_in_qkv)
                 ops.rope_store(qkv, positions, a.rotary_emb.table(residual.device), a.num_heads, a.num_kv_heads, a.head_dim,
                                a.attn.k_cache, a.attn.v_cache, ctx.slot_mapping, a.q_norm.weight, a.k_norm.weight, a.q_norm.eps)
                 q = qkv[:, :a.q_size]
             else:
                 q = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
-                                     norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws,
+                                     norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws, prefetch=pf_in_qkv,
                                      rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
                                                v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
                                                num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
             a.attn.decode_attend(q, out_packed=attn_p)
             if tp == 1:
                 ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
-                                 workspace=ws)
+                                 workspace=ws, prefetch=pf_in_o)
             else:
                 # tensor parallel: this rank's heads give a partial sum (bf16, as RowParallelLinear, layers/linear.py:185-190);
                 # one-shot all-reduce over IPC-mapped peer buffers with the residual add + fragment-packed copy in the SAME launch
@@ -419,10 +429,10 @@ class QwenForCausalLM(nn.Module):
                 ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="none", out=ybuf, workspace=ws)
                 tp_all_reduce_residual_add_pack(ybuf, residual, resid_p)
             ops.fused_linear(resid_p, fw["gate_up"][i], x_packed_rows=m, norm_folded=True, norm_eps=layer.post_attention_layernorm.eps,
-                             epilogue="silu_mul", out_packed=act_p, want_out=False, workspace=ws)
+                             epilogue="silu_mul", out_packed=act_p, want_out=False, workspace=ws, prefetch=pf_in_gu)
             if tp == 1:
                 ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
-                                 workspace=ws)
+                                 workspace=ws, prefetch=pf_in_dn)
             else:
                 ops.fused_linear(act_p, mlp.down_proj.weight, x_packed_rows=m, epilogue="none", out=ybuf, workspace=ws)
                 tp_all_reduce_residual_add_pack(ybuf, residual, resid_p)

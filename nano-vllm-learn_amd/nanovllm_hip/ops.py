@@ -342,7 +342,7 @@ _EPI_CODES = {"none": _lib.EPI_NONE, "silu_mul": _lib.EPI_SILU_MUL, "residual_ad
 
 
 def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_folded=False, epilogue="none", out=None, rope=None,
-                 x_packed_rows=None, out_packed=None, workspace=None, want_out=True, candidates=None):
+                 x_packed_rows=None, out_packed=None, workspace=None, want_out=True, candidates=None, prefetch=None):
     """nvh_linear_small_m_ex: x [M<=64, K] . weight[N, K]^T with an optional RMSNorm prologue and one of the epilogues
     "none" (+bias) | "silu_mul" | "residual_add" (out = the residual stream, updated in place) | "rope_store"
     (rope = dict(positions, cos_sin, k_cache, v_cache, slot_mapping, num_heads, num_kv_heads, head_dim); returns q [M, H*D]).
@@ -351,7 +351,9 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
     (needed for K > 1024); want_out=False skips the row-major output when out_packed is given ("none" / "silu_mul");
     candidates = (val float32 [groups, stride], idx int32 [groups, stride]) with groups = linear_candidate_groups(n, k):
     per workgroup and row the best bf16 output and its column ("none" only) — with want_out=False the outputs themselves are
-    never written (LM head + greedy arg-max in one pass; finish with greedy_advance_candidates)."""
+    never written (LM head + greedy arg-max in one pass; finish with greedy_advance_candidates).
+    prefetch = a contiguous CUDA tensor the NEXT launch will stream (the following projection's weights): the CUs this launch
+    leaves idle read it into the caches first (a hint; results do not depend on it)."""
     _require_gpu_bf16(x=x, weight=weight)
     n, k = weight.shape
     if x_packed_rows is not None:
@@ -404,6 +406,9 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
         assert cv.shape == ci.shape and cv.dim() == 2 and cv.is_contiguous() and ci.is_contiguous()
         assert cv.shape[0] >= linear_candidate_groups(n, k) > 0 and cv.shape[1] >= m
         d.candidate_val, d.candidate_idx, d.candidate_stride = cv.data_ptr(), ci.data_ptr(), cv.stride(0)
+    if prefetch is not None:
+        assert prefetch.is_cuda and prefetch.is_contiguous()
+        d.prefetch, d.prefetch_bytes = prefetch.data_ptr(), prefetch.numel() * prefetch.element_size()
     if out is None and (want_out or (out_packed is None and candidates is None)):
         out = torch.empty((m, cols), dtype=torch.bfloat16, device=x.device)
     if out is not None:
