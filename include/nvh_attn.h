@@ -290,7 +290,7 @@ typedef struct nvh_linear_desc {
        weights of the following projection.  A decode-sized projection occupies 36-224 of the device's CUs; the workgroups this
        launch adds for the idle ones read the range (default cache policy) and drop it, so that the later launch finds its operand
        in the caches.  Pure hint: results do not depend on it, only whole lines inside [prefetch, prefetch + prefetch_bytes) are
-       read, NULL / 0 = none. */
+       read, NULL / 0 = none; ranges above 4 MiB are ignored (large prefetches cost the launch more than they save). */
     const void* prefetch;
     size_t prefetch_bytes;
 } nvh_linear_desc;
