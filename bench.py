@@ -246,6 +246,7 @@ def main():
     ap.add_argument("--input-len", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no HIP graph (debug)")
+    ap.add_argument("--graph-steps", type=int, default=0, help="A/B: decode steps captured per replayed graph (0 = the session's default)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: the qkv / down launches do not prefetch the next small projection's weights")
     ap.add_argument("--prefill-leg", action="store_true", help="time the prefill attention op for models other than the headline one too")
     args = ap.parse_args()
@@ -277,6 +278,9 @@ def main():
     from nanovllm_hip.engine.sequence import Sequence
     from nanovllm_hip.models.qwen import model_config
 
+    if args.graph_steps > 0:
+        from nanovllm_hip.engine import model_runner as _mr
+        _mr.DecodeSession.MULTI = args.graph_steps
     if args.no_prefetch:
         from nanovllm_hip.models import qwen as _qwen
         _qwen.PREFETCH_WEIGHTS = False
