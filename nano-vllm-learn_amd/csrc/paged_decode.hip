@@ -332,28 +332,20 @@ __device__ __forceinline__ int32_t load_uniform_i32(const int32_t* p) {
     return *(const __attribute__((address_space(4))) int32_t*)(uintptr_t)p;
 }
 
-// write-through store / cache-bypassing load of one float (global_store_dword / global_load_dword with sc1)
-// -DNVH_HANDOFF_FENCES (cross-check build, never shipped; tools/probes/run_fence_crosscheck.sh): the SAME hand-off in the HIP
-// memory model's textbook form — plain stores, an agent-scope release fence before the ticket, an agent-scope acquire fence
-// behind it, plain loads.  +4-5 us per launch; the parity suite is run once against it to show that the fence-free form
-// computes the same thing.
+// The chunk hand-off's two flavours.  Default: the records move as write-through stores / L1-bypassing loads (sc1) and no fence is
+// needed.  -DNVH_HANDOFF_FENCES (cross-check build, never shipped; tools/probes/run_fence_crosscheck.sh): the SAME
+// hand-off in the HIP memory model's textbook form — plain stores, an agent-scope release fence before the ticket, an agent-scope
+// acquire fence behind it, plain loads.  +3-4 us per launch; the parity suite is run against it and its results are compared bit for
+// bit with the shipped form's.
 #ifdef NVH_HANDOFF_FENCES
-__device__ __forceinline__ void st_sc1(float* p, float v) { *p = v; }
-__device__ __forceinline__ float ld_sc1(const float* p) { return *p; }
 #define NVH_HANDOFF_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
 #define NVH_HANDOFF_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
 #else
-__device__ __forceinline__ void st_sc1(float* p, float v) {
-    __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float ld_sc1(const float* p) {
-    return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
 #define NVH_HANDOFF_RELEASE() do {} while (0)
 #define NVH_HANDOFF_ACQUIRE() do {} while (0)
 #endif
 
-// 16-byte forms of the same two accesses for the chunk records (buffer_store_dwordx4 / buffer_load_dwordx4 with sc1 through a raw
+// The record accesses: 16-byte items (buffer_store_dwordx4 / buffer_load_dwordx4 with sc1 through a raw
 // buffer descriptor of the (sequence, kv head)'s record group: the compiler sees them as memory operations and counts their vmcnt,
 // which inline-asm global_* accesses would leave to hand-placed waits).  Byte offsets; out-of-range accesses cannot happen (the
 // descriptor spans exactly the group).
@@ -561,8 +553,8 @@ __global__ __launch_bounds__(MW * 64) void paged_decode_split_mfma_kernel(const 
 //   * each wave owns two K + V image pairs (double buffer) and runs the online softmax over its passes without any
 //     workgroup barrier: pass p+1's LDS-DMA is issued before pass p is consumed, behind counted vmcnt waits.
 //   * the waves merge through LDS once; with more than one live chunk the workgroup publishes its (max, sum, O) record
-//     write-through (sc1 stores, vmcnt(0), barrier, ticket by a relaxed agent atomic) and the LAST ARRIVER of the
-//     (sequence, kv head) merges all records (sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
+//     write-through (16-byte sc1 stores, vmcnt(0), barrier, ticket by a relaxed agent atomic) and the LAST ARRIVER of the
+//     (sequence, kv head) merges all records (16-byte sc1 loads) and writes the output: no combine launch (-4.7 us per layer),
 //     deterministic merge order.  The release/acquire-fence form of this hand-off cost more than the launch it saved
 //     (profiles/r01_gemm_phase_stamps.txt has the same measurement for the split-K GEMM).
 template <int D, int NW, int PASS = MGeo<D>::SPLIT>
