@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NVH_VERSION 202          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch */
+#define NVH_VERSION 203          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch; 203: NVH_DECODE_CHUNKED_P256 */
 
 /* dtype codes */
 #define NVH_BF16 0
@@ -101,12 +101,14 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
  *   NVH_DECODE_CHUNKED     one launch: MFMA tiles over the GQA group, split-KV passes dealt to `chunks` workgroups per
  *                          (sequence, kv head), last-arriver combine.  waves per workgroup: 4 or 8; 0 = the default (8 at hd 64, 4 at hd 128).
  *                          chunks: 0 = one wave of workgroups over the device's CUs, > 0 = that many (clamped to the passes).
- *   NVH_DECODE_CHUNKED_P128  the chunked kernel with 128-token passes at hd 64 (16-token wave tiles; hd 128 already works that way)
+ *                          hd 64: passes of 256 tokens, or of 128 where a pair is split over 3-5 workgroups (few passes per workgroup:
+ *                          the finer passes balance the workgroups better; measured -2.5 % on average there, +1..12 % with more chunks)
+ *   NVH_DECODE_CHUNKED_P128 / _P256  the chunked kernel with the pass size forced (hd 64; 16- / 32-token wave tiles; hd 128 always uses 128)
  *   NVH_DECODE_SPLIT_MFMA  the single-pass MFMA split kernel + a combine launch (flash-decoding in two launches).
  *   NVH_DECODE_SPLIT_VALU  north_star's literal form: VALU dot products with wavefront-level (DPP / permlane) max and sum
  *                          reductions, no MFMA; groups of at most 8 query heads per kv head; + the combine launch.
  */
-enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2, NVH_DECODE_CHUNKED_P128 = 3 };
+enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2, NVH_DECODE_CHUNKED_P128 = 3, NVH_DECODE_CHUNKED_P256 = 4 };
 int nvh_paged_decode_variant(int variant, int waves, int chunks, void* out, const void* q, const void* k_cache, const void* v_cache,
                              const int32_t* block_tables, const int32_t* context_lens,
                              int batch, int h, int kvh, int hd, int block_size, int max_blocks,

@@ -1092,7 +1092,13 @@ int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
     dim3 grid(a.kvh, a.batch, a.chunks);
     const int bs_shift = (a.block_size & (a.block_size - 1)) == 0 ? __builtin_ctz(a.block_size) : -1;
     if constexpr (D == 64) {
-        if (a.pass_tokens == 128) {                            // half-size passes (nvh_paged_decode_variant: NVH_DECODE_CHUNKED_P128)
+        // Pass size at D = 64.  A pair split over 3-5 workgroups leaves each with one or two 256-token passes: whenever the pass count is not a
+        // multiple of the chunk count some workgroups carry twice the tokens of the others and the call takes as long as they do.  128-token
+        // passes (16-token wave tiles, the k = 16 MFMA) balance them: B = 32 (4 chunks) -0.5 / -1.9 / -6.6 / -4.0 / +1.9 / -3.7 / -1.9 % at ctx
+        // 600 / 1034 / 1300 / 1536 / 1800 / 2500 / 3300, B = 40 (3 chunks) -2.9 % on average, B = 24 (5) -1.2 %.  With 8 and more chunks (small
+        // batches) the passes outnumber nothing and the doubled per-pass work costs +1..12 %; with 2 chunks (B = 64) it is a wash.
+        const bool half_passes = a.pass_tokens == 128 || (a.pass_tokens == 0 && waves == 8 && a.chunks >= 3 && a.chunks <= 5);
+        if (half_passes) {
             hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8, 128>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
                                a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
             return check_launch("paged_decode_chunked");

@@ -85,7 +85,10 @@ VARIANTS = {
     "chunked_c1": dict(variant="chunked", chunks=1),
     "chunked_c3": dict(variant="chunked", chunks=3),
     "chunked_c16_w4": dict(variant="chunked", chunks=16, waves=4),
-    "chunked_p128": dict(variant="chunked_p128"),            # D = 64: 128-token passes of 16-token wave tiles
+    "chunked_p128": dict(variant="chunked_p128"),            # D = 64: 128-token passes of 16-token wave tiles (the default picks them at 3-5 chunks)
+    "chunked_p256": dict(variant="chunked_p256"),            # D = 64: 256-token passes forced
+    "chunked_c3_p256": dict(variant="chunked_p256", chunks=3),
+    "chunked_c8_p128": dict(variant="chunked_p128", chunks=8),
     "split_mfma": dict(variant="split_mfma"),
     "split_valu": dict(variant="split_valu"),
 }
