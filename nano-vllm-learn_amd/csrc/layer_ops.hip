@@ -148,6 +148,18 @@ __global__ __launch_bounds__(256) void argmax_candidates_kernel(const float* __r
     __shared__ float lds_v[4];
     __shared__ int lds_i[4];
     const int row = blockIdx.x;
+    // the row's metadata travels under the candidate loads (thread 0 owns it): the bookkeeping behind the arg-max is then stores only,
+    // and they are issued AFTER the embedding row's loads, so that the two dependent chains of the tail (token -> embedding row,
+    // context -> block table -> slot) overlap instead of following each other
+    int m_ctx = 0, m_blk = 0;
+    int64_t m_steps = 0, m_pos = 0, m_tok = 0;
+    if (threadIdx.x == 0) {
+        m_ctx = adv.context_lens[row];
+        m_steps = adv.row_steps[row];
+        m_pos = adv.positions[row];
+        m_tok = adv.input_ids[row];
+        if (m_ctx > 0) m_blk = adv.block_tables[row * adv.bt_stride + m_ctx / adv.block_size];
+    }
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     for (int gi = threadIdx.x; gi < groups; gi += 256) {
@@ -169,17 +181,42 @@ __global__ __launch_bounds__(256) void argmax_candidates_kernel(const float* __r
         // a valid token whatever the candidates held (the index feeds an embedding-row address below): the ordering above never
         // lets the (-inf, INT_MAX) identity survive a real candidate; the clamp covers corrupt candidate indices as well
         bidx = bidx < 0 ? 0 : (bidx >= vocab ? vocab - 1 : bidx);
-        if (adv.embed) lds_i[0] = adv.context_lens[row] > 0 ? bidx : (int)adv.input_ids[row];   // padding rows keep their token
-        advance_row(adv, row, bidx);
+        if (adv.embed) lds_i[0] = m_ctx > 0 ? bidx : (int)m_tok;             // padding rows keep their token
     }
+    constexpr int EMB = 4;                                                   // 16-byte chunks of the embedding row per thread: hidden <= 8192
+    u32x4 ev[EMB];
+    const uint16_t* src = nullptr;
     if (adv.embed) {
         // the next step's embedding lookup (layers/embed_head.py:34-45 at tp = 1) by the workgroup that has just chosen the token
         __syncthreads();
-        const uint16_t* src = adv.embed + (int64_t)lds_i[0] * adv.hidden;
-        for (int c = threadIdx.x * 8; c < adv.hidden; c += 256 * 8) {        // hidden % 8 == 0 (host)
+        src = adv.embed + (int64_t)lds_i[0] * adv.hidden;
+#pragma unroll
+        for (int u = 0; u < EMB; ++u) {
+            const int c = (threadIdx.x + 256 * u) * 8;
+            if (c < adv.hidden) ev[u] = *reinterpret_cast<const u32x4*>(src + c);
+        }
+    }
+    if (threadIdx.x == 0 && m_ctx > 0) {                                     // advance_row from the prefetched metadata: stores only
+        adv.tokens_log[m_steps * adv.log_stride + row] = bidx;
+        adv.row_steps[row] = m_steps + 1;
+        adv.input_ids[row] = bidx;
+        adv.positions[row] = m_pos + 1;
+        adv.context_lens[row] = m_ctx + 1;
+        adv.slot_mapping[row] = m_blk * adv.block_size + m_ctx % adv.block_size;
+    }
+    if (adv.embed) {
+#pragma unroll
+        for (int u = 0; u < EMB; ++u) {
+            const int c = (threadIdx.x + 256 * u) * 8;
+            if (c < adv.hidden) {
+                *reinterpret_cast<u32x4*>(adv.hidden_out + (int64_t)row * adv.hidden_stride + c) = ev[u];
+                // eight consecutive columns of one row are contiguous in fragment order as well
+                if (adv.hidden_packed) *reinterpret_cast<u32x4*>(adv.hidden_packed + pack_index(row, c, adv.hidden)) = ev[u];
+            }
+        }
+        for (int c = (threadIdx.x + 256 * EMB) * 8; c < adv.hidden; c += 256 * 8) {      // rows wider than 8192 (none today)
             const u32x4 v = *reinterpret_cast<const u32x4*>(src + c);
             *reinterpret_cast<u32x4*>(adv.hidden_out + (int64_t)row * adv.hidden_stride + c) = v;
-            // eight consecutive columns of one row are contiguous in fragment order as well
             if (adv.hidden_packed) *reinterpret_cast<u32x4*>(adv.hidden_packed + pack_index(row, c, adv.hidden)) = v;
         }
     }
