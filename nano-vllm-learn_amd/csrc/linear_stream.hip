@@ -228,6 +228,30 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     issue_w(tile_first, 0);
     LS_STAMP(1);
 
+    // RoPE epilogue operands of the elements this thread finishes, first half: the loads that depend on nothing but the kernel
+    // arguments (bias pair as raw bf16, cache slot, POSITION).  They are issued here, between the weight DMA and the x loads: the
+    // cos / sin loads further down hang on the position, and waiting for a position that was requested after the x loads meant
+    // draining every x load and then paying a whole round trip with nothing in flight, right in front of the MFMAs
+    uint16_t rp_b1[EPT], rp_b2[EPT];
+    int64_t rp_pos[EPT];
+    int rp_slot[EPT];
+    if constexpr (EPI == EPI_ROPE && !MULTI) {
+        int n0, n1, head, hi0;
+        tile_rows(tile_first, n0, n1, head, hi0);
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int v = tid + TPB * j, l = (v >> 2) & 63, c = l & 15;
+            const int row = min(16 * (v >> 8) + 4 * (l >> 4) + (v & 3), a.M - 1);
+            rp_pos[j] = a.positions[row];
+            rp_slot[j] = head >= a.h ? a.slots[row] : 0;
+            // unconditional (a launch without bias reads two weights instead and never uses them): a load inside `if (a.bias)` made the
+            // compiler convert the value in that very block, i.e. wait for it there with vmcnt(0) — draining the weight DMA in front of the x loads
+            const uint16_t* const bsrc = a.bias ? a.bias : p_w;
+            rp_b1[j] = bsrc[n0 + c];
+            rp_b2[j] = bsrc[n1 + c];
+        }
+    }
+
     // ---- x fragments of this wave's K range, kept in registers for every tile of the workgroup
     u32x4 araw[2 * PMAX][MT];
 #pragma unroll
@@ -258,23 +282,18 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             resid[j] = row < a.M ? reinterpret_cast<const uint16_t*>(a.out)[(int64_t)row * a.out_stride + tile_first * 16 + (l & 15)] : (uint16_t)0;
         }
     }
-    // RoPE epilogue operands of the same elements (bias pair, cos, sin, cache slot): two dependent loads deep
-    // (positions[row] -> cos_sin row), fetched here so that they travel while W is in flight
-    float rp_b1[EPT], rp_b2[EPT], rp_co[EPT], rp_si[EPT];
-    int rp_slot[EPT];
+    // RoPE operands, second half: cos and sin of the row's position (the position was requested before the x loads: waiting for it here
+    // leaves those in flight); not needed before the epilogue, see the counted wait in front of the MFMAs
+    float rp_co[EPT], rp_si[EPT];
     if constexpr (EPI == EPI_ROPE && !MULTI) {
         int n0, n1, head, hi0;
         tile_rows(tile_first, n0, n1, head, hi0);
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            const int v = tid + TPB * j, l = (v >> 2) & 63, c = l & 15;
-            const int row = min(16 * (v >> 8) + 4 * (l >> 4) + (v & 3), a.M - 1);
-            rp_b1[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n0 + c]) : 0.f;
-            rp_b2[j] = a.bias ? (float)__builtin_bit_cast(__bf16, a.bias[n1 + c]) : 0.f;
-            const float* cs = a.cos_sin + a.positions[row] * p_hd;
+            const int c = ((tid + TPB * j) >> 2) & 15;
+            const float* cs = a.cos_sin + rp_pos[j] * p_hd;
             rp_co[j] = cs[hi0 + c];
             rp_si[j] = cs[p_hd / 2 + hi0 + c];
-            rp_slot[j] = head >= a.h ? a.slots[row] : 0;
         }
     }
     LS_STAMP(2);
@@ -304,7 +323,10 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             issue_w(tile + 1, buf ^ 1);
             wait_all_but_pieces<NB * 2>(np);
         } else {
-            wait_vm<0>();
+            // RoPE epilogue: the cos / sin loads hang on positions[row] and are therefore issued last, a round trip behind everything
+            // else; they are not needed before the epilogue, so the wait in front of the MFMAs leaves the 2 * EPT youngest vector-memory
+            // operations in flight (every weight DMA and x load is older than they are: the DMA is issued first of all)
+            wait_vm<(EPI == EPI_ROPE && !MULTI) ? 2 * EPT : 0>();
         }
         if (tile == tile_first) LS_STAMP(3);
         unsigned char* const stage = lds_raw + (wave * NBUF + buf) * STAGE;
@@ -482,8 +504,10 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
             } else if constexpr (EPI == EPI_ROPE) {
                 float x1 = y[0], x2 = y[1];
                 if (a.bias) {                                              // (x + 0.f would also be exact, but keep the no-bias path add-free)
-                    x1 += rp_b1[j];
-                    x2 += rp_b2[j];
+                    uint32_t b1 = rp_b1[j], b2 = rp_b2[j];
+                    asm volatile("" : "+v"(b1), "+v"(b2));                  // the bf16 -> f32 shifts stay here, behind the MFMAs
+                    x1 += __builtin_bit_cast(float, b1 << 16);
+                    x2 += __builtin_bit_cast(float, b2 << 16);
                 }
                 x1 = (float)(__bf16)x1;                                    // the projection output is bf16 in the reference
                 x2 = (float)(__bf16)x2;
