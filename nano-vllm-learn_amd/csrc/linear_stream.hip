@@ -318,6 +318,18 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
 #pragma unroll
     for (int j = 0; j < EPT; ++j) { best_v[j] = -INFINITY; best_i[j] = 0x7fffffff; }
 
+    if constexpr (MULTI) {
+        // The x fragments are loaded once and used by every tile.  Left alone, the compiler waits for them inside the loop — with vmcnt(0),
+        // because the DMA counts behind them are run-time values — in EVERY iteration, i.e. it drains the next tile's weight DMA that was
+        // issued at the top of the iteration to travel under this tile's work (the double buffer never overlapped: found in the ISA of the
+        // LM head).  One full wait here (the first tile needs x and its weights anyway), then the fragments pass an asm pin and are plain
+        // register values for the loop, whose only vector-memory waits are then the counted ones.
+        wait_vm<0>();
+#pragma unroll
+        for (int i = 0; i < 2 * PMAX; ++i)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(araw[i][m]));
+    }
     for (int tile = tile_first, buf = 0; tile < tile_end; ++tile, buf ^= (NBUF - 1)) {
         if (MULTI && tile + 1 < tile_end) {
             issue_w(tile + 1, buf ^ 1);
