@@ -136,13 +136,17 @@ __device__ __forceinline__ void prefetch_lines(const void* base, int64_t bytes, 
 // CUs instead of 304 workgroups of 16 + 16 columns, of which 48 CUs carried two.
 // NWV = waves per workgroup (4, or 8 with half the pieces per wave: two waves per SIMD overlap each other's issue phases)
 // (p_pq, p_pr) = K pieces per split: quotient and remainder, so that no workgroup divides on the way to its first DMA
-#define LS_FLAT(a) (a).w, (a).x, (a).K, (a).N, (a).ksplit, (a).tiles, (a).inter, (a).hd, ((a).K / 64) / (a).ksplit, ((a).K / 64) % (a).ksplit, (a)
+// RESADD launches use neither `inter` nor `hd`: their two preloaded slots carry M and the row stride of the residual stream instead, and
+// the 13th / 14th preloaded dwords its address, so that the residual operand can be requested right behind the weight DMA without a
+// kernarg round trip (14 dwords = the preload count of build.py)
+#define LS_FLAT(a) (a).w, (a).x, (a).K, (a).N, (a).ksplit, (a).tiles, ((a).epi == EPI_RESADD ? (a).M : (a).inter),       \
+                   ((a).epi == EPI_RESADD ? (int)(a).out_stride : (a).hd), ((a).K / 64) / (a).ksplit, ((a).K / 64) % (a).ksplit, (a).out, (a)
 template <int MT, int EPI, int NORM, bool XPACK, bool MULTI, int PM = 4, bool WIDE = false, int NWV = 4>
 __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     // what the first W DMA and the x loads need comes first and flat: with -amdgpu-kernarg-preload-count these are in SGPRs when the
     // wave starts instead of behind a kernarg s_load (build.py); the rest of the descriptor follows by reference
     const uint16_t* __restrict__ p_w, const uint16_t* __restrict__ p_x, const int p_K, const int p_N, const int p_ksplit, const int p_tiles,
-    const int p_inter, const int p_hd, const int p_pq, const int p_pr, const LinearArgs a) {
+    const int p_inter, const int p_hd, const int p_pq, const int p_pr, void* const p_out, const LinearArgs a) {
     constexpr int SW = NWV;                                                    // (shadows the file-scope default of 4)
     constexpr int TPB = NWV * 64;                                              // threads per workgroup
     constexpr int EPT = (MT * 256 + TPB - 1) / TPB;                            // output element slots per thread
@@ -228,6 +232,20 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     issue_w(tile_first, 0);
     LS_STAMP(1);
 
+    // residual operand of RESADD for the elements this thread finishes (value v = tid + TPB j, see below), requested between the weight DMA
+    // and the x loads from preloaded arguments only (address, M, row stride: LS_FLAT).  It used to follow the x loads behind a kernarg
+    // round trip and was waited for on the spot: the last load of the launch was issued ~0.5 us late, and the MFMAs with it.  Rows past M
+    // read row M - 1 (in bounds, never used): no lane-conditional load, hence no conversion-and-wait in a block of its own
+    uint16_t resid[EPT];
+    if constexpr (EPI == EPI_RESADD && !MULTI) {
+        const int r_m = p_inter, r_stride = p_hd;                             // (see LS_FLAT)
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            const int v = tid + TPB * j, l = (v >> 2) & 63;
+            const int row = min(16 * (v >> 8) + 4 * (l >> 4) + (v & 3), r_m - 1);
+            resid[j] = reinterpret_cast<const uint16_t*>(p_out)[(int64_t)row * r_stride + tile_first * 16 + (l & 15)];
+        }
+    }
     // RoPE epilogue operands of the elements this thread finishes, first half: the loads that depend on nothing but the kernel
     // arguments (bias pair as raw bf16, cache slot, POSITION).  They are issued here, between the weight DMA and the x loads: the
     // cos / sin loads further down hang on the position, and waiting for a position that was requested after the x loads meant
@@ -270,16 +288,6 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
                     }
                 }
             }
-        }
-    }
-    // residual operand of RESADD for the elements this thread finishes (value v = tid + 256 j, see below)
-    uint16_t resid[EPT];
-    if constexpr (EPI == EPI_RESADD && !MULTI) {
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-            const int v = tid + TPB * j, l = (v >> 2) & 63;
-            const int row = 16 * (v >> 8) + 4 * (l >> 4) + (v & 3);
-            resid[j] = row < a.M ? reinterpret_cast<const uint16_t*>(a.out)[(int64_t)row * a.out_stride + tile_first * 16 + (l & 15)] : (uint16_t)0;
         }
     }
     // RoPE operands, second half: cos and sin of the row's position (the position was requested before the x loads: waiting for it here
@@ -509,7 +517,9 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
                 if (e_out_packed) e_out_packed[pack_index(row, n0 + c, p_inter)] = __builtin_bit_cast(uint16_t, o);
             } else if constexpr (EPI == EPI_RESADD) {
                 __bf16* p = out + (int64_t)row * e_out_stride + n0 + c;
-                const float old = MULTI ? (float)*p : (float)__builtin_bit_cast(__bf16, resid[j]);
+                uint32_t rraw = resid[j];
+                asm volatile("" : "+v"(rraw));                                 // the bf16 -> f32 shift stays here, behind the MFMAs
+                const float old = MULTI ? (float)*p : __builtin_bit_cast(float, rraw << 16);
                 const __bf16 o = (__bf16)(y[0] + old);
                 *p = o;
                 if (e_out_packed) e_out_packed[pack_index(row, n0 + c, p_N)] = __builtin_bit_cast(uint16_t, o);
