@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NVH_VERSION 203          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch; 203: NVH_DECODE_CHUNKED_P256 */
+#define NVH_VERSION 204          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch; 203: NVH_DECODE_CHUNKED_P256; 204: nvh_qkv_rope_attend */
 
 /* dtype codes */
 #define NVH_BF16 0
@@ -68,7 +68,8 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
  * Bytes of caller-owned scratch nvh_paged_decode needs; a pure function of the static shapes so it can be
  * allocated once before graph capture.  Layout: a fixed 64 KiB header of arrival tickets (one uint32 per
  * (sequence, kv head), each on a 128-byte line of its own: 512 pairs can be split over several workgroups, far more than the
- * device has CUs for), then the partial records of the context chunks (each padded to a 256-byte boundary).  The caller ZERO-FILLS the buffer once
+ * device has CUs for), 8 KiB of counters for nvh_qkv_rope_attend's hand-off (ready / done per kv head, one per line; a status word),
+ * then the partial records of the context chunks (each padded to a 256-byte boundary).  The caller ZERO-FILLS the buffer once
  * (hipMemset / torch.zeros); every launch returns its tickets to zero, so the buffer is reusable across calls,
  * shapes and graph replays without further clearing.  ONE launch at a time per workspace: calls that may run concurrently
  * (different streams) need a workspace each; a launch that was aborted mid-flight leaves the tickets undefined (zero-fill again).
@@ -304,6 +305,39 @@ int nvh_residual_add_pack(void* residual, const void* y, void* packed, int n_row
                           int64_t y_row_stride, int dtype, void* stream);
 size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue);
 int nvh_linear_small_m_candidate_groups(int n, int k);      /* candidate records per row of a NONE launch; 0 = unsupported shape */
+
+/*
+ * "Next" row (taken to its end): the fused qkv projection of a decode step AND the decode attention on its
+ * output as ONE launch.  Replaces the sequence nanovllm/models/qwen3.py:104-117 (qkv_proj -> rotary_emb -> self.attn) with
+ * nanovllm/layers/attention.py:84-86 (store_kvcache) and :99-101 (flash_attn_with_kvcache) inside it; the result is that of
+ * nvh_linear_small_m_ex(qkv) followed by nvh_paged_decode_packed on the q rows it wrote: q and the cache rows are the same bits, the
+ * attention output is the same bits as NVH_DECODE_CHUNKED_P128's (the formulation the one-launch kernel embeds; where nvh_paged_decode
+ * picks 256-token passes the two differ by the order in which fp32 partials are summed, i.e. by bf16 rounding noise at most).  Why one launch: the K/V stream of the attention call does not depend on the projection — only q and one cache
+ * row per (sequence, kv head) do —, so the attention workgroups start streaming with the launch and wait (bounded) only for those.
+ *   qkv            a NVH_EPI_ROPE_STORE descriptor (see nvh_linear_small_m_ex): out = the q rows [m, h*hd], k_cache / v_cache /
+ *                  slot_mapping = where this step's K / V rows go; prefetch = the output projection's weights (optional hint)
+ *   attn_out       [m, h, hd] bf16; attn_out_packed: NULL or the same rows in fragment order (as nvh_paged_decode_packed)
+ *   block_tables / context_lens / block_size / max_blocks / bt_row_stride / scale   as nvh_paged_decode (context_lens COUNT the token
+ *                  this step stores, model_runner.py:252-258; rows with context 0 give zeros)
+ *   workspace      nvh_paged_decode_workspace(m, h, hd, max_blocks, block_size) bytes, zero-filled once; the counters of the
+ *                  hand-off live in its header and are returned to zero by every launch
+ * One launch needs: hd == 64, k <= 1024 (no split-K), x_packed, norm_folded, h / kvh <= 16, kvh <= 15 and a grid of at most two
+ * workgroups per CU (all of them must be resident: consumers wait for producers), on a device this process's stream has to
+ * itself.  Every other shape runs as the two launches above, same results.  Capture-safe either way.
+ * A consumer whose wait runs out (bounded: ~1 s) writes NaN rows and sets a status word instead of hanging; read it with
+ * nvh_qkv_rope_attend_status (host-synchronous, NOT capturable) wherever the host synchronises anyway.
+ * nvh_qkv_rope_attend_variant (tests and A/B): mode 0 = as above, 1 = always two launches, 2 = one launch or NVH_E_SHAPE;
+ * spin_limit > 0 shortens the wait (polls); missing_producers > 0 makes every consumer wait for producers that do not exist (the
+ * time-out path); *one_launch (nullable) reports which form ran.
+ */
+int nvh_qkv_rope_attend(const nvh_linear_desc* qkv, void* attn_out, void* attn_out_packed,
+                        const int32_t* block_tables, const int32_t* context_lens, int block_size, int max_blocks,
+                        int64_t bt_row_stride, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int nvh_qkv_rope_attend_variant(int mode, uint32_t spin_limit, int missing_producers, int* one_launch,
+                                const nvh_linear_desc* qkv, void* attn_out, void* attn_out_packed,
+                                const int32_t* block_tables, const int32_t* context_lens, int block_size, int max_blocks,
+                                int64_t bt_row_stride, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream);
+int nvh_qkv_rope_attend_status(const void* workspace, uint32_t* timed_out);
 /* nvh_greedy_advance on candidate records instead of logits: token = column of the best candidate of each row */
 int nvh_greedy_advance_candidates(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
                                   int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,

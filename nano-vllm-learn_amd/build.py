@@ -18,8 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "nanovllm_hip", "lib")
 OBJ_DIR = os.path.join(HERE, "build")
 LIB = os.path.join(OUT_DIR, "libnvh_attn.so")
-SOURCES = ["api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip", "allreduce_oneshot.hip"]
-HEADERS = ["common.h", "kernels.h", os.path.join("..", "..", "include", "nvh_attn.h")]
+SOURCES = ["api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip", "allreduce_oneshot.hip", "qkv_attend.hip"]
+HEADERS = ["common.h", "kernels.h", "decode_chunked.h", os.path.join("..", "..", "include", "nvh_attn.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA results stay in the architectural VGPRs.  By default hipcc parks accumulators in the AGPR file
 # and pays a v_accvgpr_read/write per element wherever VALU code touches them (softmax on S, rescale of O): 159 such moves in

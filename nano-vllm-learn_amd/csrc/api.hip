@@ -85,6 +85,8 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
 }
 
 static constexpr size_t kDecodeTicketBytes = 65536;       // 512 tickets, one per 128-byte line (pairs are split over chunks only when there are few of them)
+static constexpr size_t kDecodeSyncBytes = 8192;          // behind the tickets: the ready / done counters and the status word of nvh_qkv_rope_attend
+static constexpr size_t kDecodeHeaderBytes = kDecodeTicketBytes + kDecodeSyncBytes;
 
 static int decode_num_splits(int hd, int max_blocks, int block_size) {
     const int split = decode_split_tokens(hd);
@@ -99,16 +101,17 @@ size_t nvh_paged_decode_workspace(int batch, int h, int hd, int max_blocks, int 
     // a fixed header of arrival tickets (one per (sequence, kv head); the SAME bytes whatever the shape, so that one
     // workspace serves calls of different shapes), then the partial records
     // (twice the packed size: chunk records are padded to 256-byte boundaries, at most a factor two at one query head per kv head)
-    return kDecodeTicketBytes + 2 * parts * (size_t)(hd + 2) * sizeof(float);
+    return kDecodeHeaderBytes + 2 * parts * (size_t)(hd + 2) * sizeof(float);
 }
 
-static int paged_decode_impl(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
+// validates the call and fills `a`; returns 1 when there is nothing to do (batch == 0), 0 when `a` is ready, < 0 on rejection
+static int paged_decode_args(DecodeArgs& a, void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
                              const int32_t* block_tables, const int32_t* context_lens,
                              int batch, int h, int kvh, int hd, int block_size, int max_blocks,
                              int64_t q_row_stride, int64_t bt_row_stride, float scale,
-                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream,
+                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes,
                              int variant = NVH_DECODE_CHUNKED, int waves = 0, int chunks = 0) {
-    if (batch == 0) return 0;
+    if (batch == 0) return 1;
     if (variant < NVH_DECODE_CHUNKED || variant > NVH_DECODE_CHUNKED_P256 || (waves != 0 && waves != 4 && waves != 8) || chunks < 0) {
         set_error("paged_decode: variant %d / waves %d / chunks %d not supported", variant, waves, chunks);
         return NVH_E_SHAPE;
@@ -143,7 +146,6 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
         set_error("paged_decode: workspace %zu B < required %zu B", workspace_bytes, need);
         return NVH_E_WORKSPACE;
     }
-    DecodeArgs a;
     a.out = out;
     a.q = (const uint16_t*)q;
     a.k_cache = (const uint16_t*)k_cache;
@@ -157,7 +159,7 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
     a.chunks = decode_chunks(batch, kvh, a.num_splits, chunks);
     // (decode_chunks never splits more pairs than the header has tickets for: 512, one per 128-byte line)
     a.counters = reinterpret_cast<unsigned*>(workspace);
-    a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeTicketBytes);
+    a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeHeaderBytes);
     a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;
     a.impl = (variant == NVH_DECODE_CHUNKED_P128 || variant == NVH_DECODE_CHUNKED_P256) ? NVH_DECODE_CHUNKED : variant; a.waves = waves;
     a.pass_tokens = variant == NVH_DECODE_CHUNKED_P128 ? 128 : (variant == NVH_DECODE_CHUNKED_P256 ? 256 : 0);
@@ -166,6 +168,19 @@ static int paged_decode_impl(void* out, void* out_packed, const void* q, const v
     a.scale_log2 = scale * kLog2e;
     a.out_f32 = out_dtype == NVH_F32;
     a.stamps = g_stamps;
+    return 0;
+}
+
+static int paged_decode_impl(void* out, void* out_packed, const void* q, const void* k_cache, const void* v_cache,
+                             const int32_t* block_tables, const int32_t* context_lens,
+                             int batch, int h, int kvh, int hd, int block_size, int max_blocks,
+                             int64_t q_row_stride, int64_t bt_row_stride, float scale,
+                             int dtype, int out_dtype, void* workspace, size_t workspace_bytes, void* stream,
+                             int variant = NVH_DECODE_CHUNKED, int waves = 0, int chunks = 0) {
+    DecodeArgs a;
+    const int rc = paged_decode_args(a, out, out_packed, q, k_cache, v_cache, block_tables, context_lens, batch, h, kvh, hd, block_size, max_blocks,
+                                     q_row_stride, bt_row_stride, scale, dtype, out_dtype, workspace, workspace_bytes, variant, waves, chunks);
+    if (rc) return rc > 0 ? 0 : rc;
     return launch_paged_decode(a, (hipStream_t)stream);
 }
 
@@ -390,9 +405,10 @@ int nvh_linear_small_m(void* out, const void* x, const void* w, const void* bias
     return nvh_linear_small_m_ex(&d, dtype, stream);
 }
 
-int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
+// validates the descriptor and fills `a`; returns 1 when there is nothing to do (m == 0), 0 when `a` is ready, < 0 on rejection
+static int linear_args(LinearArgs& a, const nvh_linear_desc* d, int dtype) {
     if (!d) { set_error("linear_small_m_ex: null descriptor"); return NVH_E_NULL; }
-    if (d->m == 0) return 0;
+    if (d->m == 0) return 1;
     if (dtype != NVH_BF16) { set_error("linear_small_m_ex: dtype %d unsupported (bf16 only)", dtype); return NVH_E_DTYPE; }
     const bool out_optional = (d->out_packed && (d->epilogue == NVH_EPI_NONE || d->epilogue == NVH_EPI_SILU_MUL)) ||
                               (d->candidate_val && d->epilogue == NVH_EPI_NONE);
@@ -429,7 +445,6 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
     if (d->out_packed && (!aligned16(d->out_packed) || out_cols % 32)) { set_error("linear_small_m_ex: out_packed needs 16-byte alignment and cols %% 32 == 0"); return NVH_E_ALIGN; }
     if (d->workspace && !aligned16(d->workspace)) { set_error("linear_small_m_ex: workspace must be 16-byte aligned"); return NVH_E_ALIGN; }
     if (!aligned16(d->x) || !aligned16(d->w) || (d->norm_weight && !aligned16(d->norm_weight))) { set_error("linear_small_m_ex: x, w, norm_weight must be 16-byte aligned"); return NVH_E_ALIGN; }
-    LinearArgs a;
     a.out = d->out; a.x = (const uint16_t*)d->x; a.w = (const uint16_t*)d->w; a.bias = (const uint16_t*)d->bias;
     a.M = d->m; a.N = d->n; a.K = d->k; a.inter = d->silu_inter; a.x_stride = d->x_row_stride; a.out_stride = d->out_row_stride;
     if (d->norm_folded && d->norm_weight) { set_error("linear_small_m_ex: norm_folded excludes norm_weight"); return NVH_E_NULL; }
@@ -449,6 +464,13 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
         const uintptr_t p0 = ((uintptr_t)d->prefetch + 127) & ~(uintptr_t)127, p1 = ((uintptr_t)d->prefetch + d->prefetch_bytes) & ~(uintptr_t)127;
         if (p1 > p0) { a.pf_ptr = (const void*)p0; a.pf_bytes = (int64_t)(p1 - p0); }
     }
+    return 0;
+}
+
+int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
+    LinearArgs a;
+    const int rca = linear_args(a, d, dtype);
+    if (rca) return rca > 0 ? 0 : rca;
     const int rc = launch_linear_stream(a, (hipStream_t)stream);
     if (rc != -100) return rc;
     if (d->x_packed || d->out_packed || d->candidate_val) {
@@ -460,6 +482,55 @@ int nvh_linear_small_m_ex(const nvh_linear_desc* d, int dtype, void* stream) {
 
 size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue) { return linear_stream_workspace_bytes(m, n, k, epilogue); }
 int nvh_linear_small_m_candidate_groups(int n, int k) { return linear_stream_candidate_groups(n, k); }
+
+// ---- qkv projection (RoPE / store epilogue) + decode attention
+static int qkv_rope_attend_impl(int mode, uint32_t spin_limit, int missing_producers, const nvh_linear_desc* qkv, void* attn_out, void* attn_out_packed,
+                                const int32_t* block_tables, const int32_t* context_lens, int block_size, int max_blocks,
+                                int64_t bt_row_stride, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream, int* fused_out) {
+    if (fused_out) *fused_out = 0;
+    if (!qkv) { set_error("qkv_rope_attend: null descriptor"); return NVH_E_NULL; }
+    if (qkv->epilogue != NVH_EPI_ROPE_STORE || !qkv->out) { set_error("qkv_rope_attend: the descriptor must be a ROPE_STORE projection with `out` (the q rows)"); return NVH_E_SHAPE; }
+    if (mode < 0 || mode > 2 || missing_producers < 0) { set_error("qkv_rope_attend: mode %d / missing_producers %d", mode, missing_producers); return NVH_E_SHAPE; }
+    LinearArgs l;
+    int rc = linear_args(l, qkv, dtype);
+    if (rc) return rc > 0 ? 0 : rc;
+    DecodeArgs d;
+    rc = paged_decode_args(d, attn_out, attn_out_packed, qkv->out, qkv->k_cache, qkv->v_cache, block_tables, context_lens, qkv->m, qkv->h, qkv->kvh,
+                           qkv->hd, block_size, max_blocks, qkv->out_row_stride, bt_row_stride, scale, dtype, NVH_BF16, workspace, workspace_bytes);
+    if (rc) return rc > 0 ? 0 : rc;
+    const bool can = qkv_attend_supported(l, d);
+    if (mode == 2 && !can) { set_error("qkv_rope_attend: this shape cannot run as one launch (hd 64, k <= 1024, packed x, folded norm, grid <= 2 x CUs)"); return NVH_E_SHAPE; }
+    if (mode != 1 && can) {
+        if (fused_out) *fused_out = 1;
+        return launch_qkv_attend(l, d, (unsigned char*)workspace + kDecodeTicketBytes, spin_limit, missing_producers, l.pf_ptr, l.pf_bytes, (hipStream_t)stream);
+    }
+    rc = launch_linear_stream(l, (hipStream_t)stream);
+    if (rc == -100) {
+        if (qkv->x_packed || qkv->out_packed) { set_error("qkv_rope_attend: packed activations need the streaming kernel"); return NVH_E_SHAPE; }
+        rc = launch_linear_small_m(l, (hipStream_t)stream);
+    }
+    return rc ? rc : launch_paged_decode(d, (hipStream_t)stream);
+}
+
+int nvh_qkv_rope_attend(const nvh_linear_desc* qkv, void* attn_out, void* attn_out_packed, const int32_t* block_tables, const int32_t* context_lens,
+                        int block_size, int max_blocks, int64_t bt_row_stride, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return qkv_rope_attend_impl(0, 0, 0, qkv, attn_out, attn_out_packed, block_tables, context_lens, block_size, max_blocks, bt_row_stride, scale, dtype,
+                                workspace, workspace_bytes, stream, nullptr);
+}
+
+int nvh_qkv_rope_attend_variant(int mode, uint32_t spin_limit, int missing_producers, int* fused_out, const nvh_linear_desc* qkv, void* attn_out,
+                                void* attn_out_packed, const int32_t* block_tables, const int32_t* context_lens, int block_size, int max_blocks,
+                                int64_t bt_row_stride, float scale, int dtype, void* workspace, size_t workspace_bytes, void* stream) {
+    return qkv_rope_attend_impl(mode, spin_limit, missing_producers, qkv, attn_out, attn_out_packed, block_tables, context_lens, block_size, max_blocks,
+                                bt_row_stride, scale, dtype, workspace, workspace_bytes, stream, fused_out);
+}
+
+int nvh_qkv_rope_attend_status(const void* workspace, uint32_t* timed_out) {
+    if (!workspace || !timed_out) { set_error("qkv_rope_attend_status: null pointer"); return NVH_E_NULL; }
+    const hipError_t e = hipMemcpy(timed_out, (const unsigned char*)workspace + kDecodeTicketBytes + 4096, sizeof(uint32_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("qkv_rope_attend_status: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}
 
 static int greedy_advance_candidates_impl(const float* candidate_val, const int32_t* candidate_idx, int groups, int64_t candidate_stride,
                                   int n_rows, int64_t* input_ids, int64_t* positions, int32_t* context_lens, int32_t* slot_mapping,

@@ -146,6 +146,12 @@ struct AllReduceArgs {
 int allreduce_blocks(int rows, int hidden);
 int launch_allreduce_oneshot(const AllReduceArgs& a, int blocks, hipStream_t stream);
 
+// qkv projection (RoPE / store epilogue) + decode attention in ONE launch (qkv_attend.hip)
+size_t qkv_attend_sync_bytes(void);
+bool qkv_attend_supported(const LinearArgs& l, const DecodeArgs& d);
+int launch_qkv_attend(const LinearArgs& l, const DecodeArgs& d, void* sync, unsigned spin_limit, int missing_producers, const void* pf_ptr,
+                      int64_t pf_bytes, hipStream_t stream);
+
 struct PrefillArgs {
     void* out;                   // [Tq, H, D]
     const uint16_t* q;           // [Tq, H, D], row stride q_row_stride

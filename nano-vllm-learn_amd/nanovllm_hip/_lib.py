@@ -69,6 +69,12 @@ _SIGS = {
                            [ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
     "nvh_linear_small_m_ex": (ctypes.c_int, [ctypes.POINTER(LinearDesc), ctypes.c_int, ctypes.c_void_p]),
     "nvh_linear_small_m_workspace": (ctypes.c_size_t, [ctypes.c_int] * 4),
+    "nvh_qkv_rope_attend": (ctypes.c_int, [ctypes.POINTER(LinearDesc), ctypes.c_void_p, ctypes.c_void_p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int64, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "nvh_qkv_rope_attend_variant": (ctypes.c_int, [ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(LinearDesc),
+                                                   ctypes.c_void_p, ctypes.c_void_p, _c_i32p, _c_i32p, ctypes.c_int, ctypes.c_int, ctypes.c_int64,
+                                                   ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
+    "nvh_qkv_rope_attend_status": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint32)]),
     "nvh_pack_index": (ctypes.c_int64, [ctypes.c_int] * 3),
     "nvh_linear_small_m_candidate_groups": (ctypes.c_int, [ctypes.c_int] * 2),
     "nvh_comm_alloc": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]),

@@ -46,6 +46,21 @@ class Attention(nn.Module):
                                         softmax_scale=self.scale, causal=True, out_packed=out_packed)
         return o.view(-1, self.num_heads * self.head_dim)
 
+    def qkv_rope_store_attend(self, x_packed, rows, qkv_weight, qkv_bias, norm_eps, positions, cos_sin, out_packed=None, prefetch=None,
+                              one_launch=True, linear_workspace=None):
+        """The whole front of a decode layer as ONE launch (nvh_qkv_rope_attend; SURVEY.md section 8f-2 taken to its end): the fused qkv
+        projection of the fragment-packed residual rows (RMSNorm folded into `qkv_weight`), bias, RoPE, the K/V store and the
+        decode attention on the result — the reference's qkv_proj -> rotary_emb -> self.attn (models/qwen3.py:104-117).  Shapes the
+        one-launch kernel does not serve run as the two launches, same results.  Returns the attention output [rows, H*D]."""
+        context = get_context()
+        rope = dict(positions=positions, cos_sin=cos_sin, k_cache=self.k_cache, v_cache=self.v_cache, slot_mapping=context.slot_mapping,
+                    num_heads=self.num_heads, num_kv_heads=self.num_kv_heads, head_dim=self.head_dim)
+        _, o, _ = ops.qkv_rope_attend(x_packed, qkv_weight, rope=rope, context_lens=context.context_lens, block_tables=context.block_tables,
+                                      bias=qkv_bias, norm_eps=norm_eps, norm_folded=True, x_packed_rows=rows, attn_out_packed=out_packed,
+                                      softmax_scale=self.scale, prefetch=prefetch, linear_workspace=linear_workspace,
+                                      mode="auto" if one_launch else "two_launches")
+        return o.view(-1, self.num_heads * self.head_dim)
+
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
         q = q.view(-1, self.num_heads, self.head_dim)
         k = k.view(-1, self.num_kv_heads, self.head_dim)

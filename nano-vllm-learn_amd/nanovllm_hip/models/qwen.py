@@ -277,6 +277,7 @@ class QwenDecoderLayer(nn.Module):
 
 FUSED_DECODE = True          # tests flip this to compare the fused decode layer with the plain one
 PREFETCH_WEIGHTS = True      # qkv / down launches pull the NEXT small projection's weights into the caches on their idle CUs (A/B runs flip it)
+QKV_ATTEND_ONE_LAUNCH = True # qkv projection + decode attention as ONE launch where the shape allows (nvh_qkv_rope_attend; A/B runs flip it)
 
 
 class PackedResidual:
@@ -412,13 +413,20 @@ class QwenForCausalLM(nn.Module):
                 ops.rope_store(qkv, positions, a.rotary_emb.table(residual.device), a.num_heads, a.num_kv_heads, a.head_dim,
                                a.attn.k_cache, a.attn.v_cache, ctx.slot_mapping, a.q_norm.weight, a.k_norm.weight, a.q_norm.eps)
                 q = qkv[:, :a.q_size]
+            elif xrows is not None:
+                # qkv projection (+ folded norm, bias, RoPE, K/V store) AND the decode attention on its q rows: one launch whose attention
+                # workgroups stream K/V from the first microsecond and wait only for q and the newest cache row (csrc/qkv_attend.hip)
+                a.attn.qkv_rope_store_attend(x, xrows, fw["qkv"][i], a.qkv_proj.bias, layer.input_layernorm.eps, positions,
+                                             a.rotary_emb.table(residual.device), out_packed=attn_p, prefetch=pf_in_qkv,
+                                             one_launch=QKV_ATTEND_ONE_LAUNCH, linear_workspace=ws)
             else:
                 q = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
                                      norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws, prefetch=pf_in_qkv,
                                      rope=dict(positions=positions, cos_sin=a.rotary_emb.table(residual.device), k_cache=a.attn.k_cache,
                                                v_cache=a.attn.v_cache, slot_mapping=ctx.slot_mapping, num_heads=a.num_heads,
                                                num_kv_heads=a.num_kv_heads, head_dim=a.head_dim))
-            a.attn.decode_attend(q, out_packed=attn_p)
+            if a.qk_norm or xrows is None:
+                a.attn.decode_attend(q, out_packed=attn_p)
             if tp == 1:
                 ops.fused_linear(attn_p, a.o_proj.weight, x_packed_rows=m, epilogue="residual_add", out=residual, out_packed=resid_p,
                                  workspace=ws, prefetch=pf_in_o)

@@ -77,9 +77,12 @@ def reserve_workspace(device, nbytes: int, kind: str = "chunked") -> torch.Tenso
     """Grow (never shrink) the per-device decode scratch.  Call before graph capture with the largest shape; all layers
     share it (they run back to back on ONE stream — the reference runs one process per GPU and one stream per process;
     callers that launch decode attention on several streams concurrently must pass their own `workspace=` per stream).
-    ZERO-FILLED: the chunk records of the decode kernel are self-validating granules whose tags must read "not set" before the
-    first launch; every launch stores zero back over what it consumed.  The split + combine variants (tests, A/B) keep plain
-    floats in their scratch and therefore get a buffer of their own (`kind`)."""
+    ZERO-FILLED once (the contract of nvh_attn.h): the buffer starts with a fixed header of arrival tickets (one uint32 per
+    (sequence, kv head) pair, each on a 128-byte line of its own) and the counters of the fused qkv + attention launch; the chunk
+    records behind it are plain fp32 rows published with write-through stores and need no initial value.  Every launch returns the
+    tickets and counters it used to zero, so one buffer serves all layers, shapes and graph replays; ONE launch at a time per
+    workspace; after a launch that was aborted mid-flight (a device fault, a killed process) zero-fill it again.  The split +
+    combine variants (tests, A/B) keep their partials in a buffer of their own (`kind`)."""
     idx = torch.device(device).index
     idx = torch.cuda.current_device() if idx is None else idx
     idx = (idx, kind)
@@ -354,6 +357,17 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
     never written (LM head + greedy arg-max in one pass; finish with greedy_advance_candidates).
     prefetch = a contiguous CUDA tensor the NEXT launch will stream (the following projection's weights): the CUs this launch
     leaves idle read it into the caches first (a hint; results do not depend on it)."""
+    d, out = _linear_desc(x, weight, bias=bias, norm_weight=norm_weight, norm_eps=norm_eps, norm_folded=norm_folded, epilogue=epilogue, out=out,
+                          rope=rope, x_packed_rows=x_packed_rows, out_packed=out_packed, workspace=workspace, want_out=want_out,
+                          candidates=candidates, prefetch=prefetch)
+    rc = _lib.load().nvh_linear_small_m_ex(ctypes.byref(d), NVH_BF16, _stream())
+    _lib.check(rc, "nvh_linear_small_m_ex")
+    return out
+
+
+def _linear_desc(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_folded=False, epilogue="none", out=None, rope=None,
+                 x_packed_rows=None, out_packed=None, workspace=None, want_out=True, candidates=None, prefetch=None):
+    """Build the nvh_linear_desc of fused_linear's arguments; returns (descriptor, out)."""
     _require_gpu_bf16(x=x, weight=weight)
     n, k = weight.shape
     if x_packed_rows is not None:
@@ -413,9 +427,60 @@ def fused_linear(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
         out = torch.empty((m, cols), dtype=torch.bfloat16, device=x.device)
     if out is not None:
         d.out, d.out_row_stride = out.data_ptr(), out.stride(0)
-    rc = _lib.load().nvh_linear_small_m_ex(ctypes.byref(d), NVH_BF16, _stream())
-    _lib.check(rc, "nvh_linear_small_m_ex")
-    return out
+    return d, out
+
+
+QKV_ATTEND_MODES = {"auto": 0, "two_launches": 1, "one_launch": 2}
+
+
+def qkv_rope_attend(x, weight, *, rope, context_lens, block_tables, bias=None, norm_eps=1e-6, norm_folded=True, x_packed_rows=None,
+                    q_out=None, attn_out=None, attn_out_packed=None, softmax_scale=None, workspace=None, linear_workspace=None, prefetch=None,
+                    mode="auto", spin_limit=0, missing_producers=0):
+    """nvh_qkv_rope_attend: the front of a decode layer in ONE launch — fused_linear(..., epilogue="rope_store") followed by
+    flash_attn_with_kvcache on its q rows and the caches it has just extended (models/qwen3.py:104-117 with
+    layers/attention.py:84-86 and :99-101 inside).  Shapes the one-launch kernel does not serve (head_dim 128, k > 1024,
+    row-major x, ...) run as the two launches with the same results.  Returns (q [M, H*D], attn_out [M, H, D], one_launch: bool).
+    workspace = the decode workspace (default: the per-device one); linear_workspace = fused_linear's (split-K, k > 1024 only).
+    mode / spin_limit / missing_producers: tests and A/B only (nvh_qkv_rope_attend_variant)."""
+    d, q = _linear_desc(x, weight, bias=bias, norm_eps=norm_eps, norm_folded=norm_folded, epilogue="rope_store", out=q_out, rope=rope,
+                        x_packed_rows=x_packed_rows, workspace=linear_workspace, prefetch=prefetch)
+    h, kvh, hd = rope["num_heads"], rope["num_kv_heads"], rope["head_dim"]
+    m = d.m
+    k_cache = rope["k_cache"]
+    bs = k_cache.shape[1]
+    _require_i32(context_lens=context_lens, block_tables=block_tables)
+    assert block_tables.dim() == 2 and block_tables.shape[0] == m and block_tables.stride(1) == 1
+    assert context_lens.numel() == m and context_lens.is_contiguous()
+    if attn_out is None:
+        attn_out = torch.empty((m, h, hd), dtype=torch.bfloat16, device=q.device)
+    else:
+        assert attn_out.shape == (m, h, hd) and attn_out.is_contiguous() and attn_out.dtype == torch.bfloat16
+    if attn_out_packed is not None:
+        _require_gpu_bf16(attn_out_packed=attn_out_packed)
+        assert attn_out_packed.is_contiguous() and attn_out_packed.numel() >= ((m + 15) // 16) * 16 * h * hd
+    max_blocks = block_tables.shape[1]
+    need = decode_workspace_bytes(m, h, hd, max_blocks, bs)
+    if workspace is not None:
+        assert workspace.is_cuda and workspace.dtype == torch.uint8 and workspace.is_contiguous() and workspace.numel() >= need
+        ws = workspace
+    else:
+        ws = reserve_workspace(q.device, need)
+    scale = float(hd ** -0.5 if softmax_scale is None else softmax_scale)
+    fused = ctypes.c_int(0)
+    rc = _lib.load().nvh_qkv_rope_attend_variant(
+        QKV_ATTEND_MODES[mode], int(spin_limit), int(missing_producers), ctypes.byref(fused), ctypes.byref(d), attn_out.data_ptr(),
+        attn_out_packed.data_ptr() if attn_out_packed is not None else None, block_tables.data_ptr(), context_lens.data_ptr(), bs, max_blocks,
+        block_tables.stride(0), scale, NVH_BF16, ws.data_ptr(), ws.numel(), _stream())
+    _lib.check(rc, "nvh_qkv_rope_attend")
+    return q, attn_out, bool(fused.value)
+
+
+def qkv_rope_attend_status(workspace=None, device=None) -> int:
+    """Host-synchronous: non-zero after a one-launch call whose consumers gave up waiting for a producer (its rows are NaN)."""
+    ws = workspace if workspace is not None else reserve_workspace(device if device is not None else torch.device("cuda", torch.cuda.current_device()), 1)
+    v = ctypes.c_uint32(0)
+    _lib.check(_lib.load().nvh_qkv_rope_attend_status(ws.data_ptr(), ctypes.byref(v)), "nvh_qkv_rope_attend_status")
+    return int(v.value)
 
 
 def linear_candidate_groups(n, k) -> int:

@@ -36,7 +36,7 @@ def test_version_matches_header(lib):
 def test_workspace_is_pure_function_of_static_shapes(lib):
     a = lib.nvh_paged_decode_workspace(32, 14, 64, 16, 256)
     assert a == lib.nvh_paged_decode_workspace(32, 14, 64, 16, 256) and a > 0
-    hdr = 65536                                                              # fixed ticket header, then the partial records
+    hdr = 65536 + 8192                                                       # fixed header (tickets + the fused launch's counters), then the partial records
     assert lib.nvh_paged_decode_workspace(64, 14, 64, 16, 256) - hdr == 2 * (a - hdr)
     assert lib.nvh_paged_decode_workspace(32, 14, 96, 16, 256) == 0          # unsupported head_dim
     # partial = (D + 2) floats per (row, head, split)
