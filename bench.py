@@ -248,6 +248,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no HIP graph (debug)")
     ap.add_argument("--graph-steps", type=int, default=0, help="A/B: decode steps captured per replayed graph (0 = the session's default)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: the qkv / down launches do not prefetch the next small projection's weights")
+    ap.add_argument("--two-launches", action="store_true", help="A/B: qkv projection and decode attention as two launches (not nvh_qkv_rope_attend's one)")
     ap.add_argument("--prefill-leg", action="store_true", help="time the prefill attention op for models other than the headline one too")
     args = ap.parse_args()
 
@@ -284,6 +285,9 @@ def main():
     if args.no_prefetch:
         from nanovllm_hip.models import qwen as _qwen
         _qwen.PREFETCH_WEIGHTS = False
+    if args.two_launches:
+        from nanovllm_hip.models import qwen as _qwen
+        _qwen.QKV_ATTEND_ONE_LAUNCH = False
     cfg = model_config(args.model)
     bs = cfg.kvcache_block_size
     total_len = args.input_len + args.steps + args.warmup + 2

@@ -186,28 +186,91 @@ constexpr int chunked_lds_bytes() {
     return NW * 4 * IMG + QI * 1024 + NW * 2 * 16 * 4 + 16;
 }
 
-// One poller per workgroup (lane 0 of wave 0), bounded; every wave of the workgroup leaves through the barrier.  Returns false when the
-// wait ran out.  `lds_word` is one LDS dword of the caller's.
-__device__ __forceinline__ bool fused_wait(const FusedSync& fs, int kh, int tid, unsigned* lds_word) {
-    if (tid == 0) {
-        const unsigned* const rdy = fs.ready + (int64_t)kh * kTicketStride;
-        unsigned ok = 1, spins = 0;
-        while (__hip_atomic_load(rdy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < fs.need) {     // global_load_dword sc1
-            if (++spins > fs.spin_limit) { ok = 0; break; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        if (!ok) __hip_atomic_store(fs.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned* const dn = fs.done + (int64_t)kh * kTicketStride;
-        const unsigned old = __hip_atomic_fetch_add(dn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (old == fs.consumers - 1) {                           // every consumer of the head is past its wait: reset for the next launch
-            __hip_atomic_store(fs.ready + (int64_t)kh * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(dn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *lds_word = ok;
-    }
-    __syncthreads();
-    return *lds_word != 0;
+// The poll of one wave (all lanes load the same dword: one request): FOUR polls in flight, a new one issued as the oldest returns, so
+// that a counter that completes is seen one round trip later at most (a single poll in flight sees it up to two round trips later: the
+// poll that just missed has to come back first).  One asm statement: the in-flight destination registers are nobody else's.
+// Returns 1 when the counter reached `need`, 0 after `limit` rounds of four polls.  Older vector-memory operations of the wave complete
+// first (vmcnt counts in order).
+__device__ __forceinline__ unsigned poll_counter(const unsigned* ctr, unsigned need, unsigned limit) {
+    unsigned ok, cnt, r0, r1, r2, r3;
+    asm volatile(
+        "s_mov_b32 %[cnt], %[limit]\n\t"
+        "global_load_dword %[r0], %[p], off sc1\n\t"
+        "s_sleep 3\n\t"
+        "global_load_dword %[r1], %[p], off sc1\n\t"
+        "s_sleep 3\n\t"
+        "global_load_dword %[r2], %[p], off sc1\n\t"
+        "s_sleep 3\n\t"
+        "global_load_dword %[r3], %[p], off sc1\n\t"
+        "1:\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_readfirstlane_b32 %[ok], %[r0]\n\t"
+        "s_cmp_ge_u32 %[ok], %[need]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dword %[r0], %[p], off sc1\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_readfirstlane_b32 %[ok], %[r1]\n\t"
+        "s_cmp_ge_u32 %[ok], %[need]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dword %[r1], %[p], off sc1\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_readfirstlane_b32 %[ok], %[r2]\n\t"
+        "s_cmp_ge_u32 %[ok], %[need]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dword %[r2], %[p], off sc1\n\t"
+        "s_waitcnt vmcnt(3)\n\t"
+        "v_readfirstlane_b32 %[ok], %[r3]\n\t"
+        "s_cmp_ge_u32 %[ok], %[need]\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "global_load_dword %[r3], %[p], off sc1\n\t"
+        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+        "s_cmp_lg_u32 %[cnt], 0\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[ok], 0\n\t"
+        "s_branch 3f\n\t"
+        "2:\n\t"
+        "s_mov_b32 %[ok], 1\n\t"
+        "3:\n\t"
+        "s_waitcnt vmcnt(0)"
+        : [ok] "=&s"(ok), [cnt] "=&s"(cnt), [r0] "=&v"(r0), [r1] "=&v"(r1), [r2] "=&v"(r2), [r3] "=&v"(r3)
+        : [p] "v"(ctr), [need] "s"(need), [limit] "s"(limit)
+        : "memory", "scc");
+    return ok;
 }
+
+// Wave 0 polls (bounded) and, once the producers are in, fetches the group's q rows into the workgroup's q image (L1-bypassing loads of
+// ONE wave: the eight waves of 256 workgroups asking the memory side for the same 57 KB at once queued for ~1.5 us); every wave of the
+// workgroup leaves through the barrier (an LDS-only barrier: the waves' LDS-DMA stays in flight across it).  Returns false when the wait
+// ran out.  The poller then draws the head's consumer count; fused_release() — at the END of the workgroup's work, so that the returning
+// atomic's round trip is nobody's wait — returns the counters to zero in the workgroup that drew the last one.
+template <typename StageQ>
+__device__ __forceinline__ bool fused_wait(const FusedSync& fs, int kh, int tid, unsigned* lds_word, unsigned& drawn, StageQ stage_q) {
+    drawn = 0;
+    if (tid < 64) {                                              // wave 0, all lanes
+        const unsigned ok = poll_counter(fs.ready + (int64_t)kh * kTicketStride, fs.need, (fs.spin_limit + 3) / 4);
+        stage_q();
+        if (tid == 0) *lds_word = ok;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const bool ok = *lds_word != 0;
+    if (tid == 0) {
+        if (!ok) __hip_atomic_store(fs.status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drawn = __hip_atomic_fetch_add(fs.done + (int64_t)kh * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return ok;
+}
+__device__ __forceinline__ void fused_release(const FusedSync& fs, int kh, int tid, unsigned drawn) {
+    if (tid == 0 && drawn == fs.consumers - 1) {                 // every consumer of the head is past its wait: reset for the next launch
+        __hip_atomic_store(fs.ready + (int64_t)kh * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fs.done + (int64_t)kh * kTicketStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+#ifndef NVH_FUSED_DELAY
+#define NVH_FUSED_DELAY 0    // consumers of the fused launch hold their K/V stream back by this many s_sleep(8) (512 clocks each)
+#endif
 
 // lds: chunked_lds_bytes<D, NW, PASS>() bytes, 16-byte aligned.  (split, kh, b) = (chunk, kv head, sequence) of this workgroup.
 template <int D, int NW, int PASS, bool FUSED>
@@ -265,7 +328,11 @@ __device__ __forceinline__ void decode_chunked_body(
                 if (a.out_packed) a.out_packed[pack_index(b, kh * G * D + idx, a.h * D)] = 0;
             }
         }
-        if constexpr (FUSED) fused_wait(fs, kh, tid, lds_ticket);   // (it still counts among the head's consumers)
+        if constexpr (FUSED) {                                // (it still counts among the head's consumers)
+            unsigned drawn;
+            fused_wait(fs, kh, tid, lds_ticket, drawn, [] {});
+            fused_release(fs, kh, tid, drawn);
+        }
         return;                                               // whole workgroup, uniformly
     }
     // this wave's tile in pass p starts at token p*SPLIT + wave*WT; block ids are fetched one pass ahead
@@ -342,12 +409,14 @@ __device__ __forceinline__ void decode_chunked_body(
     // ---- FUSED: everything that does not depend on this launch's own q / K / V rows starts NOW; then the hand-off wait
     constexpr int PN = (WT * LPT + 63) / 64;                  // (row, chunk) slots of one image per lane
     bool fused_ok = true, holds_new = false;                  // holds_new: one of this wave's tiles contains token ctx - 1
+    unsigned fused_drawn = 0;
     int new_tok0 = 0, new_last = 0;                           // that tile's first token; the new row's index inside it
     u32x4 nk[PN], nv[PN];
     if constexpr (FUSED) {
         const int stride = NC * SPLIT;
         uint32_t sink = 0;
         int64_t new_row_off = 0;
+        for (int i = 0; i < NVH_FUSED_DELAY; ++i) __builtin_amdgcn_s_sleep(8);   // (the producers' loads go first)
         if (tok0 < ctx) {                                     // wave-uniform
             issue_kv(tok0, bid, 0);
             if (tok0 + stride < ctx) issue_kv(tok0 + stride, bid_next, 1);
@@ -389,15 +458,26 @@ __device__ __forceinline__ void decode_chunked_body(
             const int64_t per = (lines + nwg - 1) / nwg, l0 = iwg * per, l1 = l0 + per < lines ? l0 + per : lines;
             for (int64_t l = l0 + tid; l < l1; l += WAVES * 64) sink |= *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(fs.pf_ptr) + (l << 5));
         }
-        fused_ok = fused_wait(fs, kh, tid, lds_ticket);
-        asm volatile("" ::"v"(sink));                         // (the touches are complete: the barrier waited for them)
-        if (tok0 < ctx) {
-            // q of the group, straight into the B-operand registers, and the newest K / V row for the wave that holds its tile: the
-            // handed-off bytes are read by L1-bypassing (sc1) loads only
+        NVH_STAMP(2);
+        // the q image of the workgroup, filled by wave 0 behind its poll: row R = head min(R, G - 1), chunk order swizzled as the LDS-DMA of
+        // the stand-alone kernel leaves it (the operand reads below are the same)
+        fused_ok = fused_wait(fs, kh, tid, lds_ticket, fused_drawn, [&] {
             const RawBuf qb = raw_buffer(a.q + (int64_t)b * a.q_row_stride + (int64_t)(kh * G) * D, (uint32_t)(G * D * 2));
-            const int g = lq < G ? lq : G - 1;
+            u32x4 qv[QI];
 #pragma unroll
-            for (int st = 0; st < STEPS; ++st) qf[st] = __builtin_bit_cast(bf16x8, ld16_raw_sc1(qb, (uint32_t)((g * D + (4 * st + lg) * 8) * 2)));
+            for (int i = 0; i < QI; ++i) {
+                const int R = i * TPI + dr, g = R < G ? R : G - 1;
+                qv[i] = ld16_raw_sc1(qb, (uint32_t)((g * D + (dp ^ chunk_swizzle<LPT>(R)) * 8) * 2));
+            }
+#pragma unroll
+            for (int i = 0; i < QI; ++i) *reinterpret_cast<u32x4*>(lds_q + i * 1024 + lane * 16) = qv[i];
+        });
+        NVH_STAMP(3);
+        if (tok0 < ctx) {
+            // the newest K / V row for the wave that holds its tile: the handed-off bytes are read by L1-bypassing (sc1) loads only
+#pragma unroll
+            for (int st = 0; st < STEPS; ++st)
+                qf[st] = *reinterpret_cast<const bf16x8*>(lds_q + lq * ROWB + (((4 * st + lg) ^ chunk_swizzle<LPT>(lq)) * 16));
             if (holds_new) {
                 const RawBuf kb = raw_buffer(p_k_cache + new_row_off, (uint32_t)ROWB), vb = raw_buffer(p_v_cache + new_row_off, (uint32_t)ROWB);
 #pragma unroll
@@ -408,6 +488,7 @@ __device__ __forceinline__ void decode_chunked_body(
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink) : "memory");   // this wave's two passes, its touches, q (and the newest row) have landed
     }
     if (tok0 < ctx) {                                         // wave-uniform; EXEC stays all ones inside
         if constexpr (!FUSED) {
@@ -689,7 +770,10 @@ __device__ __forceinline__ void decode_chunked_body(
         }
         __syncthreads();
         NVH_TSTAMP(4);
-        if (*lds_ticket != (unsigned)live_chunks - 1) return;  // workgroup-uniform
+        if (*lds_ticket != (unsigned)live_chunks - 1) {        // workgroup-uniform
+            if constexpr (FUSED) fused_release(fs, kh, tid, fused_drawn);
+            return;
+        }
         // the last arriver zeroes the ticket for the next launch.  Issued here, behind the barrier, and not next to the add: the
         // barrier's wait would hold the whole workgroup until this store is acknowledged (~0.2 us on the launch's critical path);
         // now it completes under the record loads (the kernel's end waits for it like for the output stores)
@@ -761,6 +845,7 @@ __device__ __forceinline__ void decode_chunked_body(
         }
     }
     NVH_STAMP(7);
+    if constexpr (FUSED) fused_release(fs, kh, tid, fused_drawn);
 }
 
 }  // namespace

@@ -52,6 +52,21 @@ __device__ __forceinline__ void st16_global_sc1(void* p, u32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
+// Diagnostic build only (-DNVH_STAMPS, tools/probes/stamp_qkv_attend.py): clock stamps of the producer role, [tile][wave][8], behind the
+// consumers' region of the debug buffer.  Never compiled into the shipped library.
+#ifdef NVH_STAMPS
+#define QA_STAMP(k)                                                                                                          \
+    do {                                                                                                                     \
+        unsigned long long t_;                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                                   \
+        if (a.stamps && lane == 0) a.stamps[((int64_t)tile * QA_WAVES + wave) * 8 + (k)] = t_;                               \
+    } while (0)
+#else
+#define QA_STAMP(k) do {} while (0)
+#endif
+
 template <int N>
 __device__ __forceinline__ void qa_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -81,6 +96,7 @@ __device__ __forceinline__ void qkv_tile_body(unsigned char* const lds_raw, cons
     const int head = tile >> ph_shift, hi0 = 16 * (tile & ((1 << ph_shift) - 1));
     const int n0 = head * p_hd + hi0, n1 = n0 + p_hd / 2;
 
+    QA_STAMP(0);
     // ---- W DMA first: one instruction = 8 rows x 128 B; 16-byte chunk order XOR-swizzled on the source (conflict-free operand reads)
     const int dr = lane >> 3, dp = lane & 7;
     const int rswz = (lq >> 1) & 7;
@@ -147,7 +163,9 @@ __device__ __forceinline__ void qkv_tile_body(unsigned char* const lds_raw, cons
     float ss2[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) ss2[m] = 0.f;
+    QA_STAMP(1);
     qa_wait_vm<2 * EPT>();                                     // everything but cos / sin (the youngest loads) has landed
+    QA_STAMP(2);
     f32x4 acc[NB][MT];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
@@ -176,6 +194,7 @@ __device__ __forceinline__ void qkv_tile_body(unsigned char* const lds_raw, cons
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // staging reads done: the buffer becomes the reduction tile
+    QA_STAMP(3);
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         float t = sum_xor16(ss2[m]);
@@ -226,6 +245,7 @@ __device__ __forceinline__ void qkv_tile_body(unsigned char* const lds_raw, cons
         }
     }
     __syncthreads();
+    QA_STAMP(4);
     // ---- results leave as 16-byte write-through stores: thread t moves columns [8 seg, 8 seg + 8) of row t >> 2 (seg = t & 3;
     // segments 0, 1 are dims hi0 .. hi0 + 15 of the head, 2, 3 the same dims + D/2)
     if (tid < MT * 64 && (tid >> 2) < a.M) {
@@ -240,12 +260,15 @@ __device__ __forceinline__ void qkv_tile_body(unsigned char* const lds_raw, cons
             st16_global_sc1(dst, val);
         }
     }
+    QA_STAMP(5);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // every storing wave: its stores are at the memory side
     __syncthreads();
+    QA_STAMP(6);
     if (tid == 0) {
         const int group = head < a.h ? head / G : (head < a.h + a.kvh ? head - a.h : head - a.h - a.kvh);
         __hip_atomic_fetch_add(e_ready + (int64_t)group * kTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    QA_STAMP(7);
 }
 
 template <int MT>
@@ -326,6 +349,7 @@ int launch_qkv_attend(const LinearArgs& l, const DecodeArgs& d_in, void* sync, u
     a.fs.spin_limit = spin_limit ? spin_limit : (1u << 20);
     a.fs.pf_ptr = pf_ptr;
     a.fs.pf_bytes = pf_bytes;
+    if (a.lin.stamps) a.lin.stamps += (int64_t)a.dec.batch * a.dec.kvh * a.dec.num_splits * QA_WAVES * 8;   // (diagnostic builds: behind the consumers' region)
     switch ((l.M + 15) / 16) {
         case 1: return launch_mt<1>(a, tiles, gz, stream);
         case 2: return launch_mt<2>(a, tiles, gz, stream);
