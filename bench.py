@@ -248,7 +248,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no HIP graph (debug)")
     ap.add_argument("--graph-steps", type=int, default=0, help="A/B: decode steps captured per replayed graph (0 = the session's default)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: the qkv / down launches do not prefetch the next small projection's weights")
-    ap.add_argument("--two-launches", action="store_true", help="A/B: qkv projection and decode attention as two launches (not nvh_qkv_rope_attend's one)")
+    ap.add_argument("--qkv-attend", default=None, choices=["two_launches", "one_launch", "two_launches_kv_prefetch", "auto"],
+                    help="A/B: how the qkv projection + decode attention front of a layer runs (nvh_qkv_rope_attend_variant)")
+    ap.add_argument("--kv-prefetch-passes", type=int, default=1)
     ap.add_argument("--prefill-leg", action="store_true", help="time the prefill attention op for models other than the headline one too")
     args = ap.parse_args()
 
@@ -285,9 +287,10 @@ def main():
     if args.no_prefetch:
         from nanovllm_hip.models import qwen as _qwen
         _qwen.PREFETCH_WEIGHTS = False
-    if args.two_launches:
+    if args.qkv_attend:
         from nanovllm_hip.models import qwen as _qwen
-        _qwen.QKV_ATTEND_ONE_LAUNCH = False
+        _qwen.QKV_ATTEND_MODE = args.qkv_attend
+        _qwen.KV_PREFETCH_PASSES = args.kv_prefetch_passes
     cfg = model_config(args.model)
     bs = cfg.kvcache_block_size
     total_len = args.input_len + args.steps + args.warmup + 2

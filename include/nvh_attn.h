@@ -307,28 +307,31 @@ size_t nvh_linear_small_m_workspace(int m, int n, int k, int epilogue);
 int nvh_linear_small_m_candidate_groups(int n, int k);      /* candidate records per row of a NONE launch; 0 = unsupported shape */
 
 /*
- * "Next" row (taken to its end): the fused qkv projection of a decode step AND the decode attention on its
- * output as ONE launch.  Replaces the sequence nanovllm/models/qwen3.py:104-117 (qkv_proj -> rotary_emb -> self.attn) with
- * nanovllm/layers/attention.py:84-86 (store_kvcache) and :99-101 (flash_attn_with_kvcache) inside it; the result is that of
- * nvh_linear_small_m_ex(qkv) followed by nvh_paged_decode_packed on the q rows it wrote: q and the cache rows are the same bits, the
- * attention output is the same bits as NVH_DECODE_CHUNKED_P128's (the formulation the one-launch kernel embeds; where nvh_paged_decode
- * picks 256-token passes the two differ by the order in which fp32 partials are summed, i.e. by bf16 rounding noise at most).  Why one launch: the K/V stream of the attention call does not depend on the projection — only q and one cache
- * row per (sequence, kv head) do —, so the attention workgroups start streaming with the launch and wait (bounded) only for those.
+ * "Next" row (taken to its end): the front of a decode layer as ONE call — the fused qkv projection
+ * (+ folded RMSNorm, bias, RoPE, K/V store) and the decode attention on its output.  Replaces the sequence nanovllm/models/qwen3.py:104-117
+ * (qkv_proj -> rotary_emb -> self.attn) with nanovllm/layers/attention.py:84-86 (store_kvcache) and :99-101 (flash_attn_with_kvcache)
+ * inside it.  Result: that of nvh_linear_small_m_ex(qkv) followed by nvh_paged_decode_packed on the q rows it wrote.
  *   qkv            a NVH_EPI_ROPE_STORE descriptor (see nvh_linear_small_m_ex): out = the q rows [m, h*hd], k_cache / v_cache /
  *                  slot_mapping = where this step's K / V rows go; prefetch = the output projection's weights (optional hint)
  *   attn_out       [m, h, hd] bf16; attn_out_packed: NULL or the same rows in fragment order (as nvh_paged_decode_packed)
  *   block_tables / context_lens / block_size / max_blocks / bt_row_stride / scale   as nvh_paged_decode (context_lens COUNT the token
  *                  this step stores, model_runner.py:252-258; rows with context 0 give zeros)
- *   workspace      nvh_paged_decode_workspace(m, h, hd, max_blocks, block_size) bytes, zero-filled once; the counters of the
- *                  hand-off live in its header and are returned to zero by every launch
- * One launch needs: hd == 64, k <= 1024 (no split-K), x_packed, norm_folded, h / kvh <= 16, kvh <= 15 and a grid of at most two
- * workgroups per CU (all of them must be resident: consumers wait for producers), on a device this process's stream has to
- * itself.  Every other shape runs as the two launches above, same results.  Capture-safe either way.
- * A consumer whose wait runs out (bounded: ~1 s) writes NaN rows and sets a status word instead of hanging; read it with
- * nvh_qkv_rope_attend_status (host-synchronous, NOT capturable) wherever the host synchronises anyway.
- * nvh_qkv_rope_attend_variant (tests and A/B): mode 0 = as above, 1 = always two launches, 2 = one launch or NVH_E_SHAPE;
- * spin_limit > 0 shortens the wait (polls); missing_producers > 0 makes every consumer wait for producers that do not exist (the
- * time-out path); *one_launch (nullable) reports which form ran.
+ *   workspace      nvh_paged_decode_workspace(m, h, hd, max_blocks, block_size) bytes, zero-filled once
+ * Three forms were built and measured on MI355X (profiles/r03_qkv_attend_*); nvh_qkv_rope_attend runs the winner,
+ * nvh_qkv_rope_attend_variant reaches all of them (tests and A/B):
+ *   mode 1  TWO launches (the projection, then the attention call).  The winner at every shape tried; mode 0 = this.
+ *   mode 2  ONE launch (csrc/qkv_attend.hip): producer workgroups compute the projection's tiles and publish q and the new K/V rows
+ *           write-through; the attention workgroups start their K/V stream with the launch and wait (bounded) only for those.  Needs
+ *           hd == 64, k <= 1024 (no split-K), x_packed, norm_folded, h / kvh <= 16, kvh <= 15 and a grid of at most two workgroups
+ *           per CU (all resident: consumers wait for producers) on a device this stream has to itself; NVH_E_SHAPE otherwise.
+ *           q and the cache rows are the same bits as mode 1's, the attention output the same bits as NVH_DECODE_CHUNKED_P128's.
+ *           2.2 us per layer SLOWER than mode 1 at Qwen2-0.5B bs = 32: the stream's 16+ MB in flight queue in front of every load of the
+ *           producer -> consumer chain.  A consumer whose wait runs out (~1 s) writes NaN rows and sets a status word instead of
+ *           hanging (nvh_qkv_rope_attend_status, host-synchronous); spin_limit > 0 shortens the wait; missing_producers > 0 makes
+ *           every consumer wait for producers that do not exist (the time-out path).
+ *   mode 3  mode 1 with the projection launch's idle CUs touching the first `spin_limit` (default 1) passes of every attention workgroup's
+ *           K/V into the caches (hd 64).  +1.3 % on the decode step with one pass, +5 % with two: a loss as well.
+ * *one_launch (nullable) reports whether the one-launch kernel ran.  Capture-safe in every mode.
  */
 int nvh_qkv_rope_attend(const nvh_linear_desc* qkv, void* attn_out, void* attn_out_packed,
                         const int32_t* block_tables, const int32_t* context_lens, int block_size, int max_blocks,

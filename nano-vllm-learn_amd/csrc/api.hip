@@ -460,6 +460,7 @@ static int linear_args(LinearArgs& a, const nvh_linear_desc* d, int dtype) {
     // Ranges above 4 MiB are ignored: the hint pays for operands whose FIRST-BYTE latency dominates their consumer (a few MB read by a
     // few dozen workgroups); 8.7 and 17.4 MB ranges measured +-0 and +1.3 % on the decode step (the prefetching workgroups outlive the launch)
     a.pf_ptr = nullptr; a.pf_bytes = 0;
+    a.pf_kv = {};
     if (d->prefetch && d->prefetch_bytes >= 256 && d->prefetch_bytes <= ((size_t)4 << 20)) {
         const uintptr_t p0 = ((uintptr_t)d->prefetch + 127) & ~(uintptr_t)127, p1 = ((uintptr_t)d->prefetch + d->prefetch_bytes) & ~(uintptr_t)127;
         if (p1 > p0) { a.pf_ptr = (const void*)p0; a.pf_bytes = (int64_t)(p1 - p0); }
@@ -490,7 +491,7 @@ static int qkv_rope_attend_impl(int mode, uint32_t spin_limit, int missing_produ
     if (fused_out) *fused_out = 0;
     if (!qkv) { set_error("qkv_rope_attend: null descriptor"); return NVH_E_NULL; }
     if (qkv->epilogue != NVH_EPI_ROPE_STORE || !qkv->out) { set_error("qkv_rope_attend: the descriptor must be a ROPE_STORE projection with `out` (the q rows)"); return NVH_E_SHAPE; }
-    if (mode < 0 || mode > 2 || missing_producers < 0) { set_error("qkv_rope_attend: mode %d / missing_producers %d", mode, missing_producers); return NVH_E_SHAPE; }
+    if (mode < 0 || mode > 3 || missing_producers < 0) { set_error("qkv_rope_attend: mode %d / missing_producers %d", mode, missing_producers); return NVH_E_SHAPE; }
     LinearArgs l;
     int rc = linear_args(l, qkv, dtype);
     if (rc) return rc > 0 ? 0 : rc;
@@ -500,9 +501,21 @@ static int qkv_rope_attend_impl(int mode, uint32_t spin_limit, int missing_produ
     if (rc) return rc > 0 ? 0 : rc;
     const bool can = qkv_attend_supported(l, d);
     if (mode == 2 && !can) { set_error("qkv_rope_attend: this shape cannot run as one launch (hd 64, k <= 1024, packed x, folded norm, grid <= 2 x CUs)"); return NVH_E_SHAPE; }
-    if (mode != 1 && can) {
+    // mode 0 (what nvh_qkv_rope_attend runs) takes the measured winner: TWO launches.  On MI355X the one-launch form loses at every
+    // decode shape tried (its K/V stream fills the memory system's queues in front of the very loads the hand-off
+    // chain waits for); it stays reachable (mode 2) and under the same parity tests.
+    if (mode == 2 && can) {
         if (fused_out) *fused_out = 1;
         return launch_qkv_attend(l, d, (unsigned char*)workspace + kDecodeTicketBytes, spin_limit, missing_producers, l.pf_ptr, l.pf_bytes, (hipStream_t)stream);
+    }
+    if (mode == 3 && d.hd == 64) {
+        // two launches, the first one's idle CUs touching the attention launch's first K/V images (its geometry: paged_decode.hip launch_chunked)
+        const int chunks = d.chunks;
+        l.pf_kv.k_cache = d.k_cache; l.pf_kv.v_cache = d.v_cache; l.pf_kv.block_tables = d.block_tables; l.pf_kv.context_lens = d.context_lens;
+        l.pf_kv.bt_stride = d.bt_row_stride; l.pf_kv.batch = d.batch; l.pf_kv.kvh = d.kvh; l.pf_kv.hd = d.hd; l.pf_kv.block_size = d.block_size;
+        l.pf_kv.chunks = chunks; l.pf_kv.pass_tokens = (chunks >= 3 && chunks <= 5) ? 128 : 256;
+        l.pf_kv.passes = spin_limit ? (int)spin_limit : 1;            // (A/B: the variant's spin_limit argument carries the number of passes here)
+        if (d.block_size % l.pf_kv.pass_tokens) l.pf_kv.k_cache = nullptr;
     }
     rc = launch_linear_stream(l, (hipStream_t)stream);
     if (rc == -100) {

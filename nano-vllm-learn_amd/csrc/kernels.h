@@ -118,6 +118,17 @@ struct LinearArgs {
     int64_t cand_stride;         // cand_*[workgroup * cand_stride + row]; ties -> lowest column (lm_head + argmax in one pass)
     const void* pf_ptr;          // nullable: bytes a LATER launch will stream (its weights): the CUs this launch leaves idle read them
     int64_t pf_bytes;            // once (default cache policy), so that the later launch finds them in the memory-side cache
+    // the same for the FIRST K/V images of the decode attention launch that follows a ROPE projection (nvh_qkv_rope_attend mode 3): the
+    // prefetching workgroups walk block_tables / context_lens and touch the rows the attention workgroups will ask for first — never the
+    // row of token ctx - 1, which this very launch writes
+    struct KvPrefetch {
+        const uint16_t* k_cache;     // null: none
+        const uint16_t* v_cache;
+        const int32_t* block_tables;
+        const int32_t* context_lens;
+        int64_t bt_stride;
+        int batch, kvh, hd, block_size, chunks, pass_tokens, passes;   // the attention launch's geometry; `passes` first passes per workgroup
+    } pf_kv;
 };
 int launch_linear_small_m(const LinearArgs& a, hipStream_t stream);
 int launch_linear_stream(const LinearArgs& a, hipStream_t stream);   // linear_stream.hip; returns -100 when the shape is not its own

@@ -130,6 +130,46 @@ __device__ __forceinline__ void prefetch_lines(const void* base, int64_t bytes, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The same for the first K/V images of the decode attention launch that follows (LinearArgs::KvPrefetch): attention workgroup w = (kv head
+// w % kvh, sequence (w / kvh) % batch, chunk w / (kvh * batch)) starts with pass `chunk` of its sequence (and goes on with chunk + chunks);
+// a pass lies inside one cache block (pass_tokens divides block_size).  One dword per 32 bytes of every live row before token ctx - 1.
+// Two phases, so that a workgroup pays two memory round trips in all: (1) one thread per (attention workgroup, pass) of this workgroup's
+// share loads the context length and the block id TOGETHER (the table index does not depend on the length) and leaves (live rows, row
+// offset) in LDS; (2) every thread touches its share of those rows.
+__device__ __forceinline__ void prefetch_kv_images(const LinearArgs::KvPrefetch& p, int idx, int n, int tid, int nthreads, unsigned char* lds) {
+    constexpr int MAXC = 64;                                      // (attention workgroup, pass) combinations per prefetching workgroup
+    int* const c_live = reinterpret_cast<int*>(lds);
+    int64_t* const c_base = reinterpret_cast<int64_t*>(lds + MAXC * 4);
+    const int total = p.kvh * p.batch * p.chunks;
+    const int mine = idx < total ? (total - idx + n - 1) / n : 0;  // attention workgroups idx, idx + n, ...
+    const int combos = min(mine * p.passes, MAXC);
+    const int64_t row = (int64_t)p.kvh * p.hd;
+    if (tid < combos) {
+        const int w = idx + (tid / p.passes) * n, ps = tid % p.passes;
+        const int kh = w % p.kvh, b = (w / p.kvh) % p.batch, chunk = w / (p.kvh * p.batch);
+        const int t0 = (chunk + ps * p.chunks) * p.pass_tokens;
+        const int slot = min(t0 / p.block_size, (int)p.bt_stride - 1);
+        const int ctx = p.context_lens[b];
+        const int blk = p.block_tables[(int64_t)b * p.bt_stride + slot];
+        const int live = min(p.pass_tokens, ctx - 1 - t0);         // rows before the newest token
+        c_live[tid] = live > 0 ? live : 0;
+        c_base[tid] = ((int64_t)blk * p.block_size + t0 % p.block_size) * row + (int64_t)kh * p.hd;
+    }
+    __syncthreads();
+    const int per_row = p.hd * 2 / 32;                            // touches per row of one head
+    uint32_t sink = 0;
+    for (int c = 0; c < combos; ++c) {
+        const int live = c_live[c];
+        const int64_t base = c_base[c];
+        for (int i = tid; i < live * per_row; i += nthreads) {
+            const int64_t off = base + (i / per_row) * row + (i % per_row) * 16;
+            sink |= *reinterpret_cast<const uint32_t*>(p.k_cache + off);
+            sink |= *reinterpret_cast<const uint32_t*>(p.v_cache + off);
+        }
+    }
+    asm volatile("" ::"v"(sink));
+}
+
 // PM = most pieces one wave may own (4; 5 where it lets a split-K launch fit the 256 CUs with equal workgroups)
 // WIDE (SILU only): a tile is 24 gate + 24 up columns held as four 16-row blocks {gate 0-15, gate 16-23, up 0-15, up 16-23}
 // (the half blocks fetch 8 rows; their other 8 MFMA columns are never stored).  4864 / 24 -> 203 equal workgroups on the 256
@@ -168,8 +208,9 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
     const int lq = lane & 15, lg = lane >> 4;
     if constexpr (!MULTI) {
         if ((int)blockIdx.x >= p_tiles) {                        // workgroup-uniform: this workgroup only prefetches (launcher: pf_ptr set)
-            prefetch_lines(a.pf_ptr, a.pf_bytes, (int)(blockIdx.y * (gridDim.x - p_tiles) + (blockIdx.x - p_tiles)),
-                           (int)((gridDim.x - p_tiles) * gridDim.y), tid, TPB);
+            const int pf_idx = (int)(blockIdx.y * (gridDim.x - p_tiles) + (blockIdx.x - p_tiles)), pf_n = (int)((gridDim.x - p_tiles) * gridDim.y);
+            if (a.pf_kv.k_cache) prefetch_kv_images(a.pf_kv, pf_idx, pf_n, tid, TPB, lds_raw);     // (first: the attention launch is the next one)
+            if (a.pf_ptr) prefetch_lines(a.pf_ptr, a.pf_bytes, pf_idx, pf_n, tid, TPB);
             return;
         }
     }
@@ -596,7 +637,7 @@ __global__ __launch_bounds__(NWV * 64) void linear_stream_kernel(
 // grid of a single-tile-per-workgroup launch: (tiles, ksplit), widened in x by prefetch workgroups for the CUs it leaves idle
 static dim3 grid_of(const LinearArgs& a) {
     int extra = 0;
-    if (a.pf_ptr && a.pf_bytes >= 128) {
+    if ((a.pf_ptr && a.pf_bytes >= 128) || a.pf_kv.k_cache) {
         const int spare = device_cus_ls() - a.tiles * a.ksplit;
         if (spare >= 8) extra = spare / a.ksplit;
     }

@@ -47,7 +47,7 @@ class Attention(nn.Module):
         return o.view(-1, self.num_heads * self.head_dim)
 
     def qkv_rope_store_attend(self, x_packed, rows, qkv_weight, qkv_bias, norm_eps, positions, cos_sin, out_packed=None, prefetch=None,
-                              one_launch=True, linear_workspace=None):
+                              mode="auto", linear_workspace=None, kv_prefetch_passes=0):
         """The whole front of a decode layer as ONE launch (nvh_qkv_rope_attend; SURVEY.md section 8f-2 taken to its end): the fused qkv
         projection of the fragment-packed residual rows (RMSNorm folded into `qkv_weight`), bias, RoPE, the K/V store and the
         decode attention on the result — the reference's qkv_proj -> rotary_emb -> self.attn (models/qwen3.py:104-117).  Shapes the
@@ -58,7 +58,7 @@ class Attention(nn.Module):
         _, o, _ = ops.qkv_rope_attend(x_packed, qkv_weight, rope=rope, context_lens=context.context_lens, block_tables=context.block_tables,
                                       bias=qkv_bias, norm_eps=norm_eps, norm_folded=True, x_packed_rows=rows, attn_out_packed=out_packed,
                                       softmax_scale=self.scale, prefetch=prefetch, linear_workspace=linear_workspace,
-                                      mode="auto" if one_launch else "two_launches")
+                                      mode=mode, spin_limit=kv_prefetch_passes)
         return o.view(-1, self.num_heads * self.head_dim)
 
     def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):

@@ -277,7 +277,8 @@ class QwenDecoderLayer(nn.Module):
 
 FUSED_DECODE = True          # tests flip this to compare the fused decode layer with the plain one
 PREFETCH_WEIGHTS = True      # qkv / down launches pull the NEXT small projection's weights into the caches on their idle CUs (A/B runs flip it)
-QKV_ATTEND_ONE_LAUNCH = True # qkv projection + decode attention as ONE launch where the shape allows (nvh_qkv_rope_attend; A/B runs flip it)
+QKV_ATTEND_MODE = "two_launches"   # how nvh_qkv_rope_attend runs the front of a decode layer (ops.QKV_ATTEND_MODES; A/B runs change it)
+KV_PREFETCH_PASSES = 1             # mode "two_launches_kv_prefetch": first passes of every attention workgroup the qkv launch touches
 
 
 class PackedResidual:
@@ -418,7 +419,8 @@ class QwenForCausalLM(nn.Module):
                 # workgroups stream K/V from the first microsecond and wait only for q and the newest cache row (csrc/qkv_attend.hip)
                 a.attn.qkv_rope_store_attend(x, xrows, fw["qkv"][i], a.qkv_proj.bias, layer.input_layernorm.eps, positions,
                                              a.rotary_emb.table(residual.device), out_packed=attn_p, prefetch=pf_in_qkv,
-                                             one_launch=QKV_ATTEND_ONE_LAUNCH, linear_workspace=ws)
+                                             mode=QKV_ATTEND_MODE, linear_workspace=ws,
+                                             kv_prefetch_passes=KV_PREFETCH_PASSES if QKV_ATTEND_MODE == "two_launches_kv_prefetch" else 0)
             else:
                 q = ops.fused_linear(x, fw["qkv"][i], x_packed_rows=xrows, bias=a.qkv_proj.bias, norm_folded=True,
                                      norm_eps=layer.input_layernorm.eps, epilogue="rope_store", workspace=ws, prefetch=pf_in_qkv,

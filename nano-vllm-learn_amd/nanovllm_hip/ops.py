@@ -430,7 +430,7 @@ def _linear_desc(x, weight, *, bias=None, norm_weight=None, norm_eps=1e-6, norm_
     return d, out
 
 
-QKV_ATTEND_MODES = {"auto": 0, "two_launches": 1, "one_launch": 2}
+QKV_ATTEND_MODES = {"auto": 0, "two_launches": 1, "one_launch": 2, "two_launches_kv_prefetch": 3}
 
 
 def qkv_rope_attend(x, weight, *, rope, context_lens, block_tables, bias=None, norm_eps=1e-6, norm_folded=True, x_packed_rows=None,

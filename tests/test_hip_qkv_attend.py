@@ -216,3 +216,15 @@ def test_a_wait_that_runs_out_gives_nan_and_a_status_not_a_hang():
     assert int(hdr[:2048 // 4 * 2].abs().sum()) == 0, "ready / done counters must be zero after the launch"
     ws[65536 + 4096:65536 + 4100].zero_()
     _check_against_two_launches(c, ws)
+
+
+def test_kv_prefetch_form_changes_nothing():
+    """Mode 3 (the projection launch's idle CUs touch the attention launch's first K/V images) is a pure hint: same bits as mode 1."""
+    c = _case(32, 14, 2, 896, [1025 + 31 * i for i in range(32)], seed=77, width=16)
+    kc1, vc1, kc2, vc2 = c["kc"].clone(), c["vc"].clone(), c["kc"].clone(), c["vc"].clone()
+    q1, o1, p1, f1 = _run(c, "two_launches", kc1, vc1)
+    q2, o2, p2, f2 = _run(c, "two_launches_kv_prefetch", kc2, vc2, spin_limit=2)
+    torch.cuda.synchronize()
+    assert not f1 and not f2
+    assert torch.equal(_bits(q1), _bits(q2)) and torch.equal(_bits(o1), _bits(o2)) and torch.equal(_bits(p1), _bits(p2))
+    assert torch.equal(_bits(kc1), _bits(kc2)) and torch.equal(_bits(vc1), _bits(vc2))
