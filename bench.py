@@ -22,6 +22,11 @@ Output: ONE JSON line on rank 0 (contract in the task statement) with these extr
   prefill       the varlen prefill attention op (nvh_prefill_varlen) timed the same way at BASELINE config 5 (one scheduler
                 batch: 128 sequences x 128 tokens) and at S = 1024 (16 sequences: one prefill batch of config 2), with flops,
                 bytes, bound = the slower of HBM and MFMA at their peaks, and the fraction of that bound achieved.
+  step_floor    the decode step with every attention call at its floor as a launch of its own (fixed 3.75 us + bytes at 6.29 TB/s) and every
+                other launch as measured: what SURVEY section 8's rows can move of `decode_step_roofline`.
+  full_window   one more replay of bench_my's whole decode window (out = in tokens: contexts in + 1 -> 2 in) after the timed region:
+                tok/s, ms per step, the step's roofline fraction, and `bench_my_tok_s` = the figure bench_my.py:27-40 defines (prefill inside).
+  attention_sweep  the decode attention call at the other BASELINE configs' shapes (config 3; config 4 per rank and at tp = 1; Qwen3-0.6B).
   cpu_baseline  the CPU port of the reference's sdpa.math attention (oracle/sdpa_math_cpu.py, "port"), timed on this host on
                 bounded samples: the bs=32 decode call of this workload, and (`config1`) BASELINE config 1's shape (bs=1,
                 in=out=512: one 512-token prefill call and decode calls over contexts 513..1024); rank 0, N = 1 only.
@@ -55,15 +60,18 @@ def decode_attn_bytes(ctxs, h, kvh, d, bs=256, with_store=True):
 
 
 @torch.inference_mode()
-def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
+def attention_leg(cfg, tp, batch, ctx, layers, iters=30, shape=None):
     """Time nvh_decode_step alone: a HIP graph of `layers` calls on distinct KV caches (no Infinity-Cache reuse
-    between calls), replayed `iters` times between two HIP events on the launching stream."""
+    between calls), replayed `iters` times between two HIP events on the launching stream.  shape = (h, kvh, d) overrides the
+    model's per-rank head shape (the attention_sweep of the other BASELINE configs)."""
     from nanovllm_hip import ops
     dev = torch.device("cuda", torch.cuda.current_device())
     from nanovllm_hip.models.qwen import tp_partition
     rank = dist.get_rank() if dist.is_initialized() else 0
     _, h, _, kvh = tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, rank)
     d, bs = cfg.head_dim, cfg.kvcache_block_size
+    if shape is not None:
+        h, kvh, d = shape
     nblk = (ctx + bs - 1) // bs
     nb = batch * nblk + 1
     gen = torch.Generator(device="cpu").manual_seed(0)
@@ -76,9 +84,13 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
     out = torch.empty(batch, h, d, device=dev, dtype=torch.bfloat16)
     ops.reserve_workspace(dev, ops.decode_workspace_bytes(batch, h, d, nblk, bs))
 
+    reps = max(1, -(-24 // layers))                # at least 24 calls per graph: the ~7 us between two replays is amortised alike in every leg
+    n_calls = reps * layers
+
     def calls():                                   # exactly what a decoder layer launches for attention at decode
-        for c in caches:                           # (the K/V store rides in the qkv projection's epilogue, nvh_linear_small_m_ex)
-            ops.flash_attn_with_kvcache(q, c[0], c[1], cl, bt, out=out)
+        for _ in range(reps):                      # (the K/V store rides in the qkv projection's epilogue, nvh_linear_small_m_ex)
+            for c in caches:                       # (the caches of one cycle exceed the 256 MiB Infinity Cache: no reuse between calls)
+                ops.flash_attn_with_kvcache(q, c[0], c[1], cl, bt, out=out)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -98,9 +110,33 @@ def attention_leg(cfg, tp, batch, ctx, layers, iters=30):
         graph.replay()
     end.record()
     torch.cuda.synchronize()
-    us = start.elapsed_time(end) * 1e3 / (iters * layers)
+    us = start.elapsed_time(end) * 1e3 / (iters * n_calls)
     nbytes = decode_attn_bytes([ctx] * batch, h, kvh, d, bs, with_store=False)
+    del graph, caches
+    torch.cuda.empty_cache()
     return us, nbytes, (h, kvh, d)
+
+
+# floor of one decode attention call as its own launch: launch boundary + dispatch ramp + first byte, then the K/V
+# stream at the rate the part sustains; the hand-off tail is NOT in it (a free hand-off)
+ATTN_FIXED_FLOOR_US = 1.25 + 0.6 + 1.9
+HBM_SUSTAINED_GBPS = 6290.0     # float4 copy, MI355X_MICROARCH.md
+
+
+def attention_sweep(cfg):
+    """The decode attention call at the other BASELINE configs (not bench lines of their own; here so that the driver's record holds
+    them): config 3 (B = 64, ctx 3072: the window mean of 2049 -> 4096), config 4's per-rank shape at tp = 4 (7 / 1 / 128) and its
+    tp = 1 shape (28 / 4 / 128) at B = 32, ctx 1536, and the reference's default model's head shape (Qwen3-0.6B: 16 / 8 / 128)."""
+    cases = [("config 3: Qwen2-0.5B bs=64 in=out=2048, window-mean context", 64, 3072, (14, 2, 64), 6),
+             ("config 4 per rank at tp=4: Qwen2-7B heads 28/4/128 -> 7/1/128, bs=32", 32, 1536, (7, 1, 128), 12),
+             ("config 4 at tp=1: Qwen2-7B heads 28/4/128, bs=32", 32, 1536, (28, 4, 128), 6),
+             ("reference default model Qwen3-0.6B heads 16/8/128, bs=32", 32, 1536, (16, 8, 128), 4)]
+    out = []
+    for name, b, ctx, shape, layers in cases:
+        us, nbytes, _ = attention_leg(cfg, 1, b, ctx, layers, iters=12, shape=shape)
+        out.append({"workload": name, "batch": b, "ctx": ctx, "shape": list(shape), "us": round(us, 2), "bytes": int(nbytes),
+                    "GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4)})
+    return out
 
 
 def pmc_traffic(cfg, tp, batch, ctx, attn_bytes):
@@ -251,6 +287,8 @@ def main():
     ap.add_argument("--qkv-attend", default=None, choices=["two_launches", "one_launch", "two_launches_kv_prefetch", "auto"],
                     help="A/B: how the qkv projection + decode attention front of a layer runs (nvh_qkv_rope_attend_variant)")
     ap.add_argument("--kv-prefetch-passes", type=int, default=1)
+    ap.add_argument("--no-full-window", action="store_true", help="skip the extra replay of bench_my's whole decode window (out = in tokens)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the attention_sweep of the other BASELINE configs")
     ap.add_argument("--prefill-leg", action="store_true", help="time the prefill attention op for models other than the headline one too")
     args = ap.parse_args()
 
@@ -271,6 +309,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
+        os.environ.setdefault("NVH_ALLREDUCE_MEASURE", "1")          # log one-shot vs RCCL at start-up (the choice does not depend on it)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -293,25 +332,26 @@ def main():
         _qwen.KV_PREFETCH_PASSES = args.kv_prefetch_passes
     cfg = model_config(args.model)
     bs = cfg.kvcache_block_size
-    total_len = args.input_len + args.steps + args.warmup + 2
+    window = max(args.steps, args.input_len) if not args.no_full_window else args.steps      # bench_my's decode phase: out = in tokens
+    total_len = args.input_len + window + args.warmup + 2
     blocks_per_seq = (total_len + bs - 1) // bs
     engine = LLMEngine(cfg, num_kvcache_blocks=args.batch * blocks_per_seq + 8, max_model_len=max(4096, total_len),
                        enforce_eager=args.eager, seed=0, warmup=True)     # start-up warmup as the reference (model_runner.py:107-121)
 
     seed(0)
     prompts = [[randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.batch)]
-    seqs = [Sequence(p, max_tokens=args.steps + 1) for p in prompts]
+    seqs = [Sequence(p, max_tokens=window + 1) for p in prompts]
 
     # ---- prefill (outside the timed decode region; timed on its own)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    engine.prefill(seqs, reserve_tokens=args.steps + args.warmup + 2)
+    engine.prefill(seqs, reserve_tokens=window + args.warmup + 2)
     torch.cuda.synchronize()
     prefill_s = time.perf_counter() - t0
     ctx0 = len(seqs[0])                                               # input_len + 1: first decode step's context
 
     # ---- decode: W untimed steps, rewind to the same context, then exactly K timed steps
-    sess = engine.runner.decode_session(seqs, args.steps + args.warmup + 1, use_graph=not args.eager)
+    sess = engine.runner.decode_session(seqs, window + args.warmup + 1, use_graph=not args.eager)
     state0 = sess.state()
     sess.step(args.warmup)
     sess.rewind(state0)
@@ -332,6 +372,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tok_s = args.batch * args.steps / elapsed
+    engine.runner.raise_if_device_failed()
+
+    # ---- the whole bench_my window (contexts in+1 -> 2 in), once more from the same start: what bench_my.py:27-40 reports for in = out
+    full = None
+    if not args.no_full_window:
+        if window == args.steps:
+            full_elapsed = elapsed
+        else:
+            sess.rewind(state0)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            sess.step(window)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            full_elapsed = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([full_elapsed], device="cuda", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                full_elapsed = float(t.item())
+        full = (window, full_elapsed)
 
     # ---- roofline leg: the attention op alone at the mean context of the timed window
     mean_ctx = ctx0 + (args.steps - 1) // 2
@@ -345,8 +408,12 @@ def main():
         del sess
         torch.cuda.empty_cache()
         prefill = {"config5_half": prefill_leg(cfg, tp, 128, 128), "s1024": prefill_leg(cfg, tp, 16, 1024, buffers=8, iters=4)}
+    sweep = None
+    if args.model == "Qwen2-0.5B" and world == 1 and not args.no_sweep:
+        sweep = attention_sweep(cfg)
     from nanovllm_hip import distributed as nvh_dist
     tp_choice = nvh_dist.last_choice
+    failed_epoch = engine.runner.comm.failed_epoch() if engine.runner.comm is not None else None
     from nanovllm_hip.models.qwen import tp_partition
     shapes = [list(tp_partition(cfg.num_attention_heads, cfg.num_key_value_heads, tp, r)) for r in range(tp)]
 
@@ -355,6 +422,9 @@ def main():
         weight_bytes = sum(p.numel() * p.element_size() for p in engine.runner.model.parameters())
         step_bytes = weight_bytes + cfg.num_hidden_layers * attn_bytes
         step_us = elapsed / args.steps * 1e6
+        layers = cfg.num_hidden_layers
+        attn_floor_us = ATTN_FIXED_FLOOR_US + attn_bytes / (HBM_SUSTAINED_GBPS * 1e3)
+        step_floor_us = step_us - layers * max(attn_us - attn_floor_us, 0.0)
         result = {
             "metric": "decode tok/s (bench_my.py) Qwen2-0.5B bs=32 in=out=1024; % HBM roofline" if args.model == "Qwen2-0.5B" and args.batch == 32
                       else f"decode tok/s (bench_my.py-shaped) {args.model} bs={args.batch}",
@@ -367,6 +437,8 @@ def main():
                        "collective": ((f"{dist.get_backend()} world_size {world} (torch.distributed; nccl = RCCL over xGMI); decode all-reduces: "
                                        + ("one-shot over IPC-mapped peer buffers with the residual add fused in (nvh_allreduce_oneshot), inside the HIP graph"
                                           if engine.runner.comm is not None else "RCCL ring through torch.distributed") + f" [{tp_choice}]") if world > 1 else "none (single GPU)"),
+                       "collective_detail": ({"path": "oneshot" if engine.runner.comm is not None else "torch.distributed",
+                                              "startup_measurement_us": nvh_dist.last_measurement, "failed_epoch": failed_epoch} if world > 1 else None),
                        "heads_per_rank_q0_qn_kv0_kvn": shapes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
@@ -376,6 +448,18 @@ def main():
             "decode_step_roofline": {"bytes_per_step": int(step_bytes), "us_at_8TBps": round(step_bytes / 8e6, 1), "us_measured": round(step_us, 1),
                                      "frac": round(step_bytes / 8e6 / step_us, 4),
                                      "attention_share_of_step": round(cfg.num_hidden_layers * attn_us / step_us, 3)},
+            # what the step would take with every attention call at its floor as a launch of its own (boundary + ramp + first byte 3.75 us,
+            # then the K/V stream at the 6.29 TB/s the part sustains, a free hand-off) and every other launch as measured: the part of the
+            # step SURVEY section 8's rows can move; the rest is the model body's launches (out of scope, hipBLASLt in the reference)
+            "step_floor": {"attention_floor_us_per_call": round(attn_floor_us, 2), "attention_measured_us_per_call": round(attn_us, 2),
+                           "us_per_step_with_attention_at_floor": round(step_floor_us, 1),
+                           "decode_step_roofline_frac_at_floor": round(step_bytes / 8e6 / step_floor_us, 4)},
+            "full_window": ({"steps": full[0], "contexts": [ctx0, ctx0 + full[0] - 1], "tok_s": round(args.batch * full[0] / full[1], 1),
+                             "ms_per_step": round(full[1] / full[0] * 1e3, 4),
+                             "decode_step_roofline_frac": round((weight_bytes + cfg.num_hidden_layers * decode_attn_bytes(
+                                 [ctx0 + (full[0] - 1) // 2] * args.batch, *shape_rank, cfg.kvcache_block_size, with_store=False)) / 8e6 / (full[1] / full[0] * 1e6), 4),
+                             "bench_my_tok_s": round(args.batch * (full[0] + 1) / (prefill_s + full[1]), 1)} if full else None),
+            "attention_sweep": sweep,
             "prefill": prefill,
             "prefill_s": round(prefill_s, 4),
             "bench_my_tok_s": round(args.batch * (args.steps + 1) / (prefill_s + elapsed), 1),

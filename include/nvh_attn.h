@@ -382,7 +382,8 @@ int64_t nvh_pack_index(int row, int col, int cols);
  *                  NVH_AR_EPI_RESIDUAL_ADD: out is the residual stream: out = bf16(out + bf16(sum)); packed (nullable): the
  *                  updated rows again in fragment order (nvh_pack_index) for the next nvh_linear_small_m_ex with x_packed
  *   stage_bytes    size of EACH rank's staging buffer (>= nvh_allreduce_stage_bytes(rows, hidden))
- *   state          uint32[16], local: [0] calls completed, [2] != 0 after a peer timed out (the epoch that failed)
+ *   state          uint32[16], local: [0] calls completed, [2] != 0 after a peer timed out OR was found two calls ahead (the epoch that
+ *                  failed; that call's rows are NaN), [3] if non-zero replaces the poll limit (tests force the time-out with it)
  * nvh_allreduce_status (host-synchronous: waits for the device, NOT capturable) reads those two words back.
  */
 #define NVH_COMM_IPC_HANDLE_BYTES 64

@@ -22,7 +22,11 @@
 // peer writes only slot (e+1) & 1; flags are compared with >=, so a flag already overwritten by e+1 still releases the wait.
 // Workgroups are independent (each owns a contiguous range of 16-byte chunks and its own flag per peer): no grid-wide sync.
 // Everything is stream-ordered and allocation-free: legal under HIP-graph capture.  A spin that runs out (a dead peer) sets
-// state[2] and writes NaN instead of hanging the device.
+// state[2] and writes NaN instead of hanging the device.  The LATE side of such an event is caught as well: a rank that finds a peer's
+// flag at e + 2 or beyond knows that peer gave up on call e (or e + 1) and has since reused the slot of parity e & 1 — the bytes it is
+// about to read may be a later call's — and fails the same way (NaN rows, state[2]) instead of summing them.  state[3], when non-zero,
+// replaces the poll limit (tests force the time-out with it); the host reads state[2] wherever it synchronises anyway
+// (nanovllm_hip/distributed.py raise_if_failed, called at the token readback).
 #include "common.h"
 #include "kernels.h"
 
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(const All
     __shared__ int lds_fail;
     const int tid = threadIdx.x, blk = blockIdx.x, nblk = gridDim.x;
     const uint32_t e = a.state[0] + 1u;                            // written by the previous launch's last workgroup
+    const uint32_t limit = a.state[3] ? a.state[3] : kArSpinLimit;
     const size_t slot = (size_t)(e & 1u) * a.slot_bytes;
     const int chunks_per_row = a.hidden / 8;                       // 16-byte chunks
     const int64_t total = (int64_t)a.rows * chunks_per_row;
@@ -61,13 +66,18 @@ __global__ __launch_bounds__(AR_THREADS) void allreduce_oneshot_kernel(const All
     if (tid < a.world && tid != a.rank) {
         const uint32_t* f = a.flags[a.rank] + (size_t)tid * AR_MAX_BLOCKS + blk;
         unsigned spins = 0;
-        while ((int32_t)(ld_sys(f) - e) < 0) {
-            if (++spins > kArSpinLimit) { lds_fail = 1; break; }
+        int32_t ahead;
+        while ((ahead = (int32_t)(ld_sys(f) - e)) < 0) {
+            if (++spins > limit) { lds_fail = 1; break; }
             __builtin_amdgcn_s_sleep(16);
         }
+        if (ahead >= 2) lds_fail = 1;                              // the peer is two calls on: it has given up on this one and reused the slot
     }
+    // acquire on BOTH sides of the barrier: the polling lanes' fence orders their own later loads; the waves that do not poll must
+    // invalidate AFTER the barrier tells them the flags were seen (their earlier invalidate proves nothing about lines fetched since)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     const bool failed = lds_fail != 0;                             // workgroup-uniform
     if (failed && tid == 0) st_sys(a.state + 2, e);
 

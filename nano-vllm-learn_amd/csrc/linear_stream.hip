@@ -117,17 +117,17 @@ __device__ __forceinline__ void prefetch_lines(const void* base, int64_t bytes, 
     const int64_t per = (lines + n - 1) / n;
     const int64_t l0 = idx * per, l1 = l0 + per < lines ? l0 + per : lines;
     const unsigned char* const b = reinterpret_cast<const unsigned char*>(base);
+    // compiler-visible loads OR-ed into one value that an empty asm consumes behind the loop: the destination registers stay live until
+    // their data has landed (an inline-asm load into a dead register could be handed to another value while still in flight)
+    uint32_t sink = 0;
     for (int64_t l = l0 + tid; l < l1; l += 8 * nthreads) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t ll = l + (int64_t)u * nthreads;
-            if (ll < l1) {
-                unsigned sink;
-                asm volatile("global_load_dword %0, %1, off" : "=v"(sink) : "v"(b + (ll << SH)) : "memory");
-            }
+            if (ll < l1) sink |= *reinterpret_cast<const uint32_t*>(b + (ll << SH));
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::"v"(sink));
 }
 
 // The same for the first K/V images of the decode attention launch that follows (LinearArgs::KvPrefetch): attention workgroup w = (kv head

@@ -147,6 +147,16 @@ class OneShotAllReduce:
         self._launch(residual, y, packed, AR_EPI_RESIDUAL_ADD)
         return residual
 
+    def set_spin_limit(self, polls: int):
+        """Tests: replace the kernel's poll limit (state[3]; 0 restores the default of ~seconds)."""
+        import numpy as np
+        v = torch.from_numpy(np.array([polls], dtype=np.uint32).view(np.int32)).to(self.device)
+        hip = ctypes.CDLL("libamdhip64.so.7")                                   # already mapped by torch: same runtime instance
+        torch.cuda.synchronize(self.device)
+        rc = hip.hipMemcpy(ctypes.c_void_p(self._state + 12), ctypes.c_void_p(v.data_ptr()), ctypes.c_size_t(4), ctypes.c_int(3))   # device to device
+        assert rc == 0, rc
+        torch.cuda.synchronize(self.device)
+
     def failed_epoch(self) -> int:
         """0, or the call number at which a peer failed to show up (the kernel then wrote NaN rows instead of hanging)."""
         calls, failed = ctypes.c_uint32(0), ctypes.c_uint32(0)
@@ -198,17 +208,53 @@ def _time_us(fn, dev, group, iters=30):
     return start.elapsed_time(end) * 1e3 / iters
 
 
-def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_oneshot: bool = True, measure: bool = True):
-    """Choose the all-reduce path for this process group, the same on every rank: one-shot over IPC if EVERY rank managed to set it
-    up AND passed the self-test AND (with an RCCL group, `measure`) it is not slower than RCCL on a decode-sized message timed
-    right here, RCCL otherwise.  Returns the OneShotAllReduce or None (= use dist.all_reduce).  `last_choice` says why."""
-    global _comm, last_choice
+def raise_if_failed(group=None):
+    """Call wherever the host synchronises anyway (token readback, end of a generation): if the one-shot all-reduce of ANY rank marked a
+    failed call (a peer that never showed up, or one found two calls ahead), EVERY rank raises — the affected rows are NaN and the
+    tokens chosen from them are garbage; nothing downstream should see them.  No-op without the one-shot path."""
+    comm = _comm
+    if comm is None:
+        return
+    failed = comm.failed_epoch()
+    t = torch.tensor([failed], dtype=torch.int64, device=comm.device if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    worst = int(t.item())
+    if worst:
+        raise RuntimeError(f"one-shot all-reduce failed at call {worst} on some rank (this rank: {failed or 'ok'}): a peer did not arrive in time; "
+                           "the residual stream of that step is NaN and its tokens are invalid")
+
+
+def close_tensor_parallel_comm():
+    """Unmap / free the process-wide one-shot communicator (every rank, after the last call)."""
+    global _comm
+    if _comm is not None:
+        _comm.close()
+        _comm = None
+
+
+def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_oneshot: bool = True, measure: bool | None = None):
+    """Choose the all-reduce path for this process group, the same on every rank and the same on every run: one-shot over IPC if EVERY
+    rank managed to set it up AND passed the self-test, RCCL otherwise.  NVH_ALLREDUCE=rccl forces the fallback, =oneshot insists (an error
+    if the set-up fails).  The two paths round differently (one-shot: fp32 sum in rank order, one rounding; the RCCL ring rounds at every
+    hop), so the choice must not depend on a timing: the comparison with RCCL (`measure`, default only with NVH_ALLREDUCE_MEASURE=1) is
+    LOGGED in `last_choice` / `last_measurement`, never acted on.  Returns the OneShotAllReduce or None (= use dist.all_reduce)."""
+    import os
+    global _comm, last_choice, last_measurement
+    close_tensor_parallel_comm()                                                # a second engine in one process: drop the first one's mappings
+    want = os.environ.get("NVH_ALLREDUCE", "").lower()
+    if measure is None:
+        measure = os.environ.get("NVH_ALLREDUCE_MEASURE") == "1"
+    if want == "rccl":
+        prefer_oneshot = False
+    last_measurement = None
     _comm, last_choice = None, "torch.distributed (single rank, no GPU, or one-shot not requested)"
     if not (dist.is_initialized() and dist.get_world_size(group) > 1 and prefer_oneshot and torch.cuda.is_available()):
         return None
     try:
         comm = OneShotAllReduce(max_rows, hidden, group=group)                # raises on EVERY rank if it failed on any (agreed inside)
     except RuntimeError as e:                                                    # e.g. IPC not available between these processes
+        if want == "oneshot":
+            raise
         import warnings
         warnings.warn(f"{e}; falling back to RCCL (dist.all_reduce)")
         last_choice = f"torch.distributed: {e}"
@@ -230,10 +276,12 @@ def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_one
         t = torch.tensor([t_one, t_rccl], dtype=torch.float64, device=comm.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)                  # the slowest rank's view, identical everywhere
         t_one, t_rccl = float(t[0]), float(t[1])
-        note = f"one-shot {t_one:.1f} us vs RCCL {t_rccl:.1f} us per [{x.shape[0]}, {hidden}] bf16 all-reduce (eager launches, max over ranks)"
-        if t_one > t_rccl:
-            problems = [f"slower than RCCL here: {note}"]
+        last_measurement = {"oneshot_us": round(t_one, 2), "rccl_us": round(t_rccl, 2), "rows": int(x.shape[0]), "hidden": int(hidden)}
+        note += f"; measured (logged only): one-shot {t_one:.1f} us vs RCCL {t_rccl:.1f} us per [{x.shape[0]}, {hidden}] bf16 all-reduce, eager launches, max over ranks"
     if problems:
+        if want == "oneshot":
+            comm.close()
+            raise RuntimeError("NVH_ALLREDUCE=oneshot but the one-shot path is not usable: " + "; ".join(problems))
         import warnings
         warnings.warn("one-shot all-reduce not used: " + "; ".join(problems))
         comm.close()
@@ -244,6 +292,7 @@ def init_tensor_parallel_comm(max_rows: int, hidden: int, group=None, prefer_one
 
 
 last_choice = "not initialised"
+last_measurement = None       # {"oneshot_us", "rccl_us", "rows", "hidden"} when init_tensor_parallel_comm timed both paths (logged, not acted on)
 
 
 def tensor_parallel_comm():

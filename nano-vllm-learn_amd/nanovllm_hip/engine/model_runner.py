@@ -149,7 +149,26 @@ class ModelRunner:
             hidden = hidden[last]
         tokens = greedy_tokens(self.model.compute_logits(hidden))
         reset_context()
-        return tokens.tolist()
+        out = tokens.tolist()                                                         # (the host synchronises here anyway)
+        self.raise_if_device_failed()
+        return out
+
+    def raise_if_device_failed(self):
+        """At a point where the host has synchronised: a time-out marked by one of the bounded device-side waits (the one-shot all-reduce of
+        any rank; the one-launch qkv + attention form) must surface as an error on every rank, not as garbage tokens."""
+        if self.comm is not None:
+            from ..distributed import raise_if_failed
+            raise_if_failed()
+        from ..models import qwen
+        if qwen.QKV_ATTEND_MODE in ("one_launch", "auto") and self.device.type == "cuda" and ops.qkv_rope_attend_status(device=self.device):
+            raise RuntimeError("nvh_qkv_rope_attend (one launch): a consumer's wait for the projection's producers ran out; the step's rows are NaN")
+
+    def close(self):
+        """Release the tensor-parallel communicator's IPC mappings (every rank, after the last step)."""
+        if self.comm is not None:
+            from ..distributed import close_tensor_parallel_comm
+            close_tensor_parallel_comm()
+            self.comm = None
 
     def decode_session(self, seqs, max_new_tokens, use_graph=True):
         return DecodeSession(self, seqs, max_new_tokens, use_graph)
@@ -355,6 +374,7 @@ class DecodeSession:
     def finish(self):
         """Copy generated tokens back into the host sequences (one device->host sync for the whole generation)."""
         toks = self.tokens[: self.steps_done].cpu().tolist()
+        self.runner.raise_if_device_failed()                                          # (behind the sync of the readback)
         for row in toks:
             for s, t in zip(self.seqs, row):
                 s.append_token(int(t))

@@ -176,3 +176,104 @@ def test_tensor_parallel_engine_oneshot_graph_equals_collective_eager():
     assert sorted(ret.keys()) == [0, 1]
     for same_paths, same_ranks, n in ret.values():
         assert same_paths and same_ranks and n == 24
+
+
+def _timeout_worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, "nano-vllm-learn_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nanovllm_hip import distributed as D
+        comm = D.init_tensor_parallel_comm(MAX_ROWS, HIDDEN)
+        assert comm is not None and D.last_measurement is None           # the choice is the self-test's alone; nothing was timed
+        comm.set_spin_limit(200)                                          # ~ a millisecond instead of seconds
+        dev = torch.device("cuda:0")
+        x = torch.ones(8, HIDDEN, dtype=torch.bfloat16, device=dev)
+        dist.barrier()
+        if rank == 0:
+            # three calls nobody answers: each gives up, writes NaN and marks the failure; its flags at the peer now read 3 calls ahead
+            for _ in range(3):
+                y = x.clone()
+                comm.all_reduce(y)
+                torch.cuda.synchronize()
+                assert torch.isnan(y.float()).all(), "a timed-out all-reduce must not return plausible numbers"
+            assert comm.failed_epoch() != 0
+        dist.barrier()
+        if rank == 1:
+            # the LATE rank: its peer's flag satisfies the wait at once, but is two calls ahead — the slot it would read has been
+            # reused; it must fail as well instead of summing a later call's bytes
+            y = x.clone()
+            comm.all_reduce(y)
+            torch.cuda.synchronize()
+            assert torch.isnan(y.float()).all(), "the late rank summed a reused slot"
+            assert comm.failed_epoch() != 0
+        dist.barrier()
+        raised = False
+        try:
+            D.raise_if_failed()                                           # what the engine calls at its token readback: EVERY rank raises
+        except RuntimeError as e:
+            raised = "one-shot all-reduce failed" in str(e)
+        D.close_tensor_parallel_comm()
+        ret[rank] = raised
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_timeout_surfaces_as_an_error_on_every_rank():
+    """a rank whose peer never arrives writes NaN and marks state[2]; the late peer finds the flag two calls ahead
+    and fails too; the host-side check at a sync point raises on every rank instead of letting arg-max pick tokens from NaN rows."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29900 + (os.getpid() + 57) % 300
+    mp.spawn(_timeout_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert dict(ret) == {0: True, 1: True}
+
+
+def _fallback_worker(rank, world, port, ret):
+    for p in (ROOT, os.path.join(ROOT, "nano-vllm-learn_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from nanovllm_hip import distributed as D
+        from nanovllm_hip.engine.llm_engine import LLMEngine
+        from nanovllm_hip.models.qwen import model_config
+        if rank == 1:                                                     # IPC export fails on ONE rank only
+            def boom(self, ptr):
+                raise RuntimeError("injected: hipIpcGetMemHandle refused")
+            D.OneShotAllReduce._export = boom
+        cfg = model_config("Qwen2-0.5B", num_hidden_layers=2, vocab_size=2048)
+        g = torch.Generator().manual_seed(0)
+        prompts = [torch.randint(0, 2048, (n,), generator=g).tolist() for n in (300, 17, 256, 5)]
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            eng = LLMEngine(cfg, num_kvcache_blocks=16, enforce_eager=False, seed=1)
+        fell_back = eng.runner.comm is None and D.tensor_parallel_comm() is None and "injected" in D.last_choice
+        toks = eng.generate(prompts, max_tokens=12)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, toks)
+        ret[rank] = (fell_back, all(t == gathered[0] for t in gathered), len(toks[0]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ipc_failure_on_one_rank_makes_every_rank_fall_back():
+    """The fallback DECISION path (torch.distributed instead of the one-shot kernel) when the IPC set-up fails on one rank: injected on
+    rank 1 of a two-process rehearsal on cuda:0; both ranks must take the collective path, say why, and produce the same tokens."""
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29900 + (os.getpid() + 211) % 300
+    mp.spawn(_fallback_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert sorted(ret.keys()) == [0, 1]
+    for fell_back, same, n in ret.values():
+        assert fell_back and same and n == 12
