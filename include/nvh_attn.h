@@ -104,12 +104,14 @@ int nvh_paged_decode(void* out, const void* q, const void* k_cache, const void* 
  *                          chunks: 0 = one wave of workgroups over the device's CUs, > 0 = that many (clamped to the passes).
  *                          hd 64: passes of 256 tokens, or of 128 where a pair is split over 3-5 workgroups (few passes per workgroup:
  *                          the finer passes balance the workgroups better; measured -2.5 % on average there, +1..12 % with more chunks)
- *   NVH_DECODE_CHUNKED_P128 / _P256  the chunked kernel with the pass size forced (hd 64; 16- / 32-token wave tiles; hd 128 always uses 128)
+ *   NVH_DECODE_CHUNKED_P128 / _P256 / _P64  the chunked kernel with the pass size forced: hd 64 takes 128 or 256 (16- / 32-token wave tiles),
+ *                          hd 128 takes 128 or 64 (four waves x 32- / 16-token tiles; the default picks 64 where a pair is split over at most
+ *                          8 workgroups: -5 % at Qwen2-7B's per-rank shape 7/1/128, bs 32); a size the head_dim does not have is ignored
  *   NVH_DECODE_SPLIT_MFMA  the single-pass MFMA split kernel + a combine launch (flash-decoding in two launches).
  *   NVH_DECODE_SPLIT_VALU  north_star's literal form: VALU dot products with wavefront-level (DPP / permlane) max and sum
  *                          reductions, no MFMA; groups of at most 8 query heads per kv head; + the combine launch.
  */
-enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2, NVH_DECODE_CHUNKED_P128 = 3, NVH_DECODE_CHUNKED_P256 = 4 };
+enum { NVH_DECODE_CHUNKED = 0, NVH_DECODE_SPLIT_MFMA = 1, NVH_DECODE_SPLIT_VALU = 2, NVH_DECODE_CHUNKED_P128 = 3, NVH_DECODE_CHUNKED_P256 = 4, NVH_DECODE_CHUNKED_P64 = 5 };
 int nvh_paged_decode_variant(int variant, int waves, int chunks, void* out, const void* q, const void* k_cache, const void* v_cache,
                              const int32_t* block_tables, const int32_t* context_lens,
                              int batch, int h, int kvh, int hd, int block_size, int max_blocks,

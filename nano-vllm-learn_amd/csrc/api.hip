@@ -112,7 +112,7 @@ static int paged_decode_args(DecodeArgs& a, void* out, void* out_packed, const v
                              int dtype, int out_dtype, void* workspace, size_t workspace_bytes,
                              int variant = NVH_DECODE_CHUNKED, int waves = 0, int chunks = 0) {
     if (batch == 0) return 1;
-    if (variant < NVH_DECODE_CHUNKED || variant > NVH_DECODE_CHUNKED_P256 || (waves != 0 && waves != 4 && waves != 8) || chunks < 0) {
+    if (variant < NVH_DECODE_CHUNKED || variant > NVH_DECODE_CHUNKED_P64 || (waves != 0 && waves != 4 && waves != 8) || chunks < 0) {
         set_error("paged_decode: variant %d / waves %d / chunks %d not supported", variant, waves, chunks);
         return NVH_E_SHAPE;
     }
@@ -161,8 +161,9 @@ static int paged_decode_args(DecodeArgs& a, void* out, void* out_packed, const v
     a.counters = reinterpret_cast<unsigned*>(workspace);
     a.ws_acc = reinterpret_cast<float*>((unsigned char*)workspace + kDecodeHeaderBytes);
     a.ws_ml = a.ws_acc + (size_t)batch * h * a.num_splits * hd;
-    a.impl = (variant == NVH_DECODE_CHUNKED_P128 || variant == NVH_DECODE_CHUNKED_P256) ? NVH_DECODE_CHUNKED : variant; a.waves = waves;
-    a.pass_tokens = variant == NVH_DECODE_CHUNKED_P128 ? 128 : (variant == NVH_DECODE_CHUNKED_P256 ? 256 : 0);
+    // (a pass size the head_dim does not have — 256 at hd 128, 64 at hd 64 — leaves the default choice in place)
+    a.impl = variant >= NVH_DECODE_CHUNKED_P128 ? NVH_DECODE_CHUNKED : variant; a.waves = waves;
+    a.pass_tokens = variant == NVH_DECODE_CHUNKED_P128 ? 128 : (variant == NVH_DECODE_CHUNKED_P256 ? 256 : (variant == NVH_DECODE_CHUNKED_P64 ? 64 : 0));
     a.out_packed = (uint16_t*)out_packed;
     a.q_row_stride = q_row_stride; a.bt_row_stride = bt_row_stride;
     a.scale_log2 = scale * kLog2e;

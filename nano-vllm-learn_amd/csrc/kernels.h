@@ -30,7 +30,7 @@ struct DecodeArgs {
     uint16_t* out_packed;        // nullable: bf16 output also in MFMA-fragment order [ceil(B/16)][H*D/32][64][8] (pack_index)
     int impl;                    // 0 chunked MFMA (default), 1 split MFMA + combine, 2 split VALU + combine (nvh_paged_decode_variant)
     int waves;                   // chunked kernel: 0 / 8 = eight waves per workgroup, 4 = four
-    int pass_tokens;             // chunked kernel, D = 64: 0 = chosen from the chunk count, 128 / 256 = forced (16- / 32-token wave tiles)
+    int pass_tokens;             // chunked kernel: 0 = chosen from the chunk count; forced: 128 / 256 at D = 64, 64 / 128 at D = 128
 };
 
 // tokens one workgroup of the split kernel covers (static function of head_dim)

@@ -38,6 +38,13 @@
 #include "kernels.h"
 #include "decode_chunked.h"
 
+#ifndef NVH_D128_HALF_RULE
+#define NVH_D128_HALF_RULE(chunks) ((chunks) <= 8)   // the chunk counts at which head_dim 128 takes 64-token passes by default.  Measured (same box,
+                             // B = 32, 64- against 128-token passes, ctx 1034 / 1536 / 2048 / 3072): 7/1/128 (8 chunks) 8.02 / 8.81 / 9.95 / 12.76 against
+                             // 8.25 / 9.27 / 10.23 / 12.74 us; 28/4/128 (2 chunks) -3 % everywhere; 16/8/128 (1 chunk) -0.2 .. -1 %; 7/1/128 at B = 64 (4 chunks)
+                             // -1.3 %, B = 16 (16 chunks) +1.3 %, B = 8 (32 chunks) +9 %: with 128-token passes twelve passes over eight chunks leave half the
+                             // workgroups with twice the tokens of the others; with many chunks the finer passes only add per-pass work
+#endif
 #ifndef NVH_D128_WAVES
 #define NVH_D128_WAVES 4     // waves per workgroup of the chunked kernel at head_dim 128 when the caller does not choose (4 or 8).
                              // With 4-byte records 8 waves won (7/1/128 ctx 1536: 11.1 vs 12.1 us); since the records move as 16-byte items
@@ -526,6 +533,16 @@ int launch_chunked(const DecodeArgs& a, int g, hipStream_t stream) {
         const bool half_passes = a.pass_tokens == 128 || (a.pass_tokens == 0 && waves == 8 && a.chunks >= 3 && a.chunks <= 5);
         if (half_passes) {
             hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 8, 128>), grid, dim3(8 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
+                               a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
+            return check_launch("paged_decode_chunked");
+        }
+    }
+    if constexpr (D == 128) {
+        // Pass size at D = 128: 64-token passes (four waves x 16-token tiles, the k = 16 MFMA) where 128-token passes leave some workgroups of a pair
+        // with twice the tokens of the others (NVH_D128_HALF_RULE below; a.pass_tokens = 64 / 128 forces either)
+        const bool half_passes = a.pass_tokens == 64 || (a.pass_tokens == 0 && a.waves == 0 && NVH_D128_HALF_RULE(a.chunks));   // (pass_tokens 128 forces the full pass)
+        if (half_passes) {
+            hipLaunchKernelGGL((paged_decode_chunked_kernel<D, 4, 64>), grid, dim3(4 * 64), 0, stream, a.context_lens, a.block_tables, a.k_cache, a.v_cache,
                                a.kvh, a.block_size, a.max_blocks, a.chunks, (int)a.bt_row_stride, bs_shift, a, g);
             return check_launch("paged_decode_chunked");
         }

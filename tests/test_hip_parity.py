@@ -89,6 +89,8 @@ VARIANTS = {
     "chunked_p256": dict(variant="chunked_p256"),            # D = 64: 256-token passes forced
     "chunked_c3_p256": dict(variant="chunked_p256", chunks=3),
     "chunked_c8_p128": dict(variant="chunked_p128", chunks=8),
+    "chunked_p64": dict(variant="chunked_p64"),              # D = 128: 64-token passes of four 16-token wave tiles (the default picks them at <= 8 chunks)
+    "chunked_c16_p64": dict(variant="chunked_p64", chunks=16),
     "split_mfma": dict(variant="split_mfma"),
     "split_valu": dict(variant="split_valu"),
 }

@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time a HIP graph of `layers` back-to-back launches")
     ap.add_argument("--fused", action="store_true", help="decode: time nvh_decode_step (store + attend)")
     ap.add_argument("--seq", type=int, default=1024, help="prefill: sequence length")
-    ap.add_argument("--variant", default=None, help="decode: chunked | chunked_p128 | chunked_p256 | split_mfma | split_valu (nvh_paged_decode_variant); prefill: auto | tiled | short")
+    ap.add_argument("--variant", default=None, help="decode: chunked | chunked_p64 | chunked_p128 | chunked_p256 | split_mfma | split_valu (nvh_paged_decode_variant); prefill: auto | tiled | short")
     ap.add_argument("--waves", type=int, default=0, help="decode (chunked, D=64): 4 or 8 waves; prefill short kernel: 8 or 16")
     ap.add_argument("--chunks", type=int, default=0, help="decode (chunked): workgroups per (sequence, kv head)")
     args = ap.parse_args()
