@@ -11,7 +11,7 @@ for rep in 1 2 3; do
 for lib in "" ${BASE:-tools/probes/ab/base.so}; do
   export NVH_LIB_PATH=$lib; [ -z "$lib" ] && unset NVH_LIB_PATH
   echo "# lib ${lib:-new} rep $rep" >> gpurun_out/gab/bench.log
-  timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> gpurun_out/gab/bench.log || exit 1
+  timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> gpurun_out/gab/bench.log || exit 1
 done
 done
 paste - - < gpurun_out/gab/bench.log

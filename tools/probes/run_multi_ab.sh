@@ -10,7 +10,7 @@ rm -f gpurun_out/multi/bench.log
 for rep in 1 2 3; do
 for n in 1 4 8 16; do
   echo "# graph-steps $n rep $rep" >> gpurun_out/multi/bench.log
-  timeout -k 10 200 python bench.py --steps 208 --warmup 16 --no-cpu-baseline --graph-steps $n 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> gpurun_out/multi/bench.log || exit 1
+  timeout -k 10 200 python bench.py --steps 208 --warmup 16 --no-cpu-baseline --graph-steps $n 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'])" >> gpurun_out/multi/bench.log || exit 1
 done
 done
 paste - - < gpurun_out/multi/bench.log

@@ -6,7 +6,7 @@ run() {  # $1 = kernel substring, rest = program args
   for set in "${sets[@]}"; do
     i=$((i+1))
     timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmcf_$i -- python3 tools/microbench.py "$@" --iters 3 --warmup 1 > gpurun_out/pmcf_$i.log 2>&1
-    f=$(ls gpurun_out/pmcf_$i/*/*counter_collection.csv 2>/dev/null | head -1)
+    f=$(ls gpurun_out/pmcf_$i/*/*counter_collection.csv 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | head -1)
     if [ -n "$f" ]; then python3 tools/pmc_kernel.py $f $k; else tail -3 gpurun_out/pmcf_$i.log; fi
     rm -rf gpurun_out/pmcf_$i
   done

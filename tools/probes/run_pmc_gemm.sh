@@ -6,7 +6,7 @@ i=0
 for set in "${sets[@]}"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmcg_$i -- python3 bench.py --steps 48 --warmup 2 --eager --no-cpu-baseline > gpurun_out/pmcg_$i.log 2>&1
-  f=$(ls gpurun_out/pmcg_$i/*/*counter_collection.csv 2>/dev/null | head -1)
+  f=$(ls gpurun_out/pmcg_$i/*/*counter_collection.csv 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | head -1)
   if [ -n "$f" ]; then
     for k in "linear_stream_kernel<2, 2, 0, true, false, 2, false, 8>" "linear_stream_kernel<2, 2, 0, true, false, 3, false, 8>" "linear_stream_kernel<2, 1, 2, true, false, 2, true, 8>" "linear_stream_kernel<2, 3, 2, true, false, 2, false, 8>" "paged_decode_chunked_kernel"; do
       echo "# $k"; python3 tools/pmc_kernel.py $f "$k"

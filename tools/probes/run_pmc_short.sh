@@ -6,7 +6,7 @@ i=0
 for set in "${sets[@]}"; do
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $set --kernel-trace --output-format csv -d gpurun_out/pmcs_$i -- python3 tools/microbench.py prefill --batch 128 --seq 128 --iters 3 --warmup 1 > gpurun_out/pmcs_$i.log 2>&1
-  f=$(ls gpurun_out/pmcs_$i/*/*counter_collection.csv 2>/dev/null | head -1)
+  f=$(ls gpurun_out/pmcs_$i/*/*counter_collection.csv 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | head -1)
   if [ -n "$f" ]; then python3 tools/pmc_kernel.py $f prefill_short; else tail -3 gpurun_out/pmcs_$i.log; fi
   rm -rf gpurun_out/pmcs_$i
 done

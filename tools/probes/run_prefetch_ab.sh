@@ -10,7 +10,7 @@ rm -f gpurun_out/pfab/bench.log
 for rep in 1 2 3; do
 for flag in "" "--no-prefetch"; do
   echo "# ${flag:-prefetch} rep $rep" >> gpurun_out/pfab/bench.log
-  timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline $flag 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['us_per_launch'])" >> gpurun_out/pfab/bench.log || exit 1
+  timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline $flag 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['value'], d['roofline']['us_per_launch'])" >> gpurun_out/pfab/bench.log || exit 1
 done
 done
 paste - - < gpurun_out/pfab/bench.log

@@ -12,5 +12,5 @@ for v in one two; do
 done
 for v in one two one two; do
   flag=""; [ $v = two ] && flag="--two-launches"
-  timeout -k 10 300 python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline $flag 2>/dev/null | tail -1 | cut -c1-190
+  timeout -k 10 300 python3 bench.py --steps 200 --warmup 5 --no-cpu-baseline $flag 2>>${NVH_PROBE_ERR:-gpurun_out/probe_stderr.log} | tail -1 | cut -c1-190
 done
