@@ -126,7 +126,25 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     // under the causal mask tile t costs t+1 key tiles, and dispatching the heaviest tiles of every (sequence, head) first
     // leaves the light ones for the tail (census in tools/probes/stamp_prefill.py: the old x = q-tile order spent the last
     // 40 % of the launch draining a few heavy workgroups that had started late)
-    const int qt = gridDim.z - 1 - blockIdx.z, head = blockIdx.x, b = blockIdx.y;
+    int qt = gridDim.z - 1 - blockIdx.z, head = blockIdx.x, b = blockIdx.y;
+#ifndef NVH_PREFILL_NO_XCD_MAP
+    {
+        // XCD-aware order (speed only; any mapping is correct): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its
+        // own, so in the plain order the G heads x q-tiles that stream the SAME K/V rows of a (sequence, kv head) pair land on all eight
+        // and each L2 fetches those rows for itself.  Re-deal: linear workgroup id -> (XCD = id % 8, index on that XCD); pair u lives on
+        // XCD u % 8, and on its XCD the order is heads of the group fastest, then the XCD's pairs, then q-tiles heaviest first — so every
+        // XCD still works through the same mix of heavy and light tiles.
+        const int G = a.h / a.kvh, units = (int)gridDim.y * a.kvh, total = (int)(gridDim.x * gridDim.y * gridDim.z);
+        if ((units & 7) == 0 && (total & 7) == 0) {
+            const int lin = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
+            const int xcd = lin & 7, idx = lin >> 3, per = units >> 3;
+            const int g_in = idx % G, r = idx / G, u = xcd + 8 * (r % per), z = r / per;
+            b = u / a.kvh;
+            head = (u - b * a.kvh) * G + g_in;
+            qt = (int)gridDim.z - 1 - z;
+        }
+    }
+#endif
     const int q_beg = a.cu_q[b], q_end = a.cu_q[b + 1];
     const int k_beg = a.cu_k[b], k_end = a.cu_k[b + 1];
     const int sq = q_end - q_beg, sk = k_end - k_beg;
