@@ -17,7 +17,7 @@ Output: ONE JSON line on rank 0 (contract in the task statement) with these extr
   roofline      the decode attention op (nvh_paged_decode: one chunked split-KV launch, combine included) at the mean context of the
                 timed window, timed live with HIP events on the launching stream over a graph of per-layer calls
                 on distinct caches; achieved = algorithmic bytes / average time per call; traffic = HBM bytes per call from the
-                committed rocprofv3 PMC passes (profiles/r02_pmc_decode_traffic.json), taken at the profiled context nearest to
+                committed rocprofv3 PMC passes (profiles/r03_pmc_decode_traffic.json), taken at the profiled context nearest to
                 the measured one and scaled by the ratio of algorithmic bytes (the line says which context it came from).
   prefill       the varlen prefill attention op (nvh_prefill_varlen) timed the same way at BASELINE config 5 (one scheduler
                 batch: 128 sequences x 128 tokens) and at S = 1024 (16 sequences: one prefill batch of config 2), with flops,
@@ -140,12 +140,12 @@ def attention_sweep(cfg):
 
 
 def pmc_traffic(cfg, tp, batch, ctx, attn_bytes):
-    """HBM bytes per attention call from the committed rocprofv3 PMC passes (profiles/r02_pmc_decode_traffic.json: one
+    """HBM bytes per attention call from the committed rocprofv3 PMC passes (profiles/r03_pmc_decode_traffic.json: one
     --pmc FETCH_SIZE and one --pmc WRITE_SIZE pass of tools/microbench.py per profiled context; FETCH_SIZE doubled per the
     gfx950 correction, + WRITE_SIZE).  The record of the profiled context nearest to `ctx` is scaled by the ratio of
     algorithmic bytes (measured / algorithmic is 1.04-1.06 at every profiled context: the kernel reads each K/V byte once).
     Returns (bytes, note) or (None, reason)."""
-    for name in ("r02_pmc_decode_traffic.json", "r01_pmc_decode_traffic.json"):
+    for name in ("r03_pmc_decode_traffic.json", "r02_pmc_decode_traffic.json", "r01_pmc_decode_traffic.json"):
         try:
             p = json.load(open(os.path.join(ROOT, "profiles", name)))
             break

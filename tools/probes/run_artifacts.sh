@@ -1,5 +1,5 @@
 # Round artifacts: default bench line, rocprofv3 kernel stats of the same command, decode / prefill sweeps.
-R=${R:-r02}
+R=${R:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python3 bench.py > gpurun_out/bench_default.log 2>&1; tail -1 gpurun_out/bench_default.log > gpurun_out/${R}_bench_default_line.json
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_def -- python3 bench.py --no-cpu-baseline > gpurun_out/bench_prof.log 2>&1

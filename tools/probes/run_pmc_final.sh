@@ -17,7 +17,7 @@ echo "# prefill_varlen_kernel<128,false,2> B=4 S=4096 H/KVH/D=16/8/128"
 run prefill_varlen prefill --batch 4 --seq 4096 --heads 16 --kv-heads 8 --head-dim 128
 echo "# paged_decode_chunked_kernel<64, 8, 128>  B=32 ctx=1536 width 16 (eager launches; 128-token passes: four chunks per pair)"
 run paged_decode_chunked decode --batch 32 --ctx 1536 --width 16
-echo "# paged_decode_chunked_kernel<128, 4, 128>  B=32 ctx=1536 H/KVH/D=7/1/128 (eager launches; four waves, 32-token wave tiles)"
+echo "# paged_decode_chunked_kernel<128, 4, 64>  B=32 ctx=1536 H/KVH/D=7/1/128 (eager launches; four waves, 16-token wave tiles, 64-token passes)"
 run paged_decode_chunked decode --batch 32 --ctx 1536 --heads 7 --kv-heads 1 --head-dim 128
 echo "# prefill_short_kernel<64,2,16>  B=128 S=128 H/KVH/D=14/2/64 (BASELINE config 5, one scheduler batch)"
 run prefill_short prefill --batch 128 --seq 128
