@@ -159,25 +159,6 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     const int lq = lane & 15;                        // query column of this lane
     const int lg = lane >> 4;                        // lane group: k-block of the operands / key rows of C
 
-    // ---- Q fragments (B operand of S^T): Q[row][32*step + 8*lg .. +8]; plain loads, retired before any DMA is issued
-    int my_q[QT];                                    // query index inside the sequence, per sub-tile
-    bool q_ok[QT];
-    bf16x8 qf[QT][STEPS];
-#pragma unroll
-    for (int qs = 0; qs < QT; ++qs) {
-        my_q[qs] = q0 + wave * WR + 16 * qs + lq;
-        q_ok[qs] = my_q[qs] < sq;
-        const uint16_t* qp = a.q + (int64_t)(q_beg + (q_ok[qs] ? my_q[qs] : sq - 1)) * a.q_row_stride + (int64_t)head * D + lg * 8;
-#pragma unroll
-        for (int st = 0; st < STEPS; ++st) {
-            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + st * 32);
-            qf[qs][st] = *reinterpret_cast<const bf16x8*>(&raw);
-        }
-    }
-    PF_STAMP(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PF_STAMP(1);
-
     f32x4 o[QT][DT];
     float m_run[QT], l_run[QT];                      // per query column; l_run is this lane group's share
 #pragma unroll
@@ -243,6 +224,24 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
     };
 
     stage(0, 0);
+    // ---- Q fragments (B operand of S^T): Q[row][32*step + 8*lg .. +8]; plain loads issued BEHIND the first tile's DMA, so that a workgroup
+    // pays one memory latency at its start, not two in a row (the counted wait of the first tile body leaves only tile 1's DMA in flight:
+    // vector-memory operations complete in order, so tile 0 and these loads have landed by then)
+    int my_q[QT];                                    // query index inside the sequence, per sub-tile
+    bool q_ok[QT];
+    bf16x8 qf[QT][STEPS];
+#pragma unroll
+    for (int qs = 0; qs < QT; ++qs) {
+        my_q[qs] = q0 + wave * WR + 16 * qs + lq;
+        q_ok[qs] = my_q[qs] < sq;
+        const uint16_t* qp = a.q + (int64_t)(q_beg + (q_ok[qs] ? my_q[qs] : sq - 1)) * a.q_row_stride + (int64_t)head * D + lg * 8;
+#pragma unroll
+        for (int st = 0; st < STEPS; ++st) {
+            const u32x4 raw = *reinterpret_cast<const u32x4*>(qp + st * 32);
+            qf[qs][st] = *reinterpret_cast<const bf16x8*>(&raw);
+        }
+    }
+    PF_STAMP(0);
     // tr-read: lane 4q+p of its group addresses key row q, dims 4p..4p+3.  The per-lane part of the address (row 4*lg+q,
     // swizzled chunk of dim tile t) is loop invariant: DT registers; buffer, image, 32-key half and the +16-row partner are
     // immediates of the instruction (hence the tile loop unrolled by two: the buffer index must be a compile-time constant).

@@ -9,7 +9,7 @@ echo "# decode attention call (nvh_paged_decode), HIP-graph of 24 calls, block-t
 for c in 1025 1536 2048; do timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --ctx $c; done
 echo "# config 3: B=64"
 for c in 2049 3072 4096; do timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --batch 64 --ctx $c; done
-echo "# config 4 per-rank shape (Qwen2-7B tp=4: 7/1/128), 8 waves (default) and 4"
+echo "# config 4 per-rank shape (Qwen2-7B tp=4: 7/1/128): the default (four waves, 64-token passes since round 3), then --waves 4 (four waves, 128-token passes: the round-2 default)"
 timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --heads 7 --kv-heads 1 --head-dim 128 --ctx 1536
 timeout -k 10 100 python3 tools/microbench.py decode --graph --width 16 --heads 7 --kv-heads 1 --head-dim 128 --ctx 1536 --waves 4
 echo "# Qwen2-7B tp=1 head shape (28/4/128)"
