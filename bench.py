@@ -307,6 +307,7 @@ def main():
     rehearse = os.environ.get("NVH_BENCH_REHEARSE") == "gloo"
     if rehearse:
         local_rank = 0
+        args.no_full_window = True                 # (ranks time-share one GPU: a dry run of the code path, kept short)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("NVH_ALLREDUCE_MEASURE", "1")          # log one-shot vs RCCL at start-up (the choice does not depend on it)
