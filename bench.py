@@ -166,7 +166,7 @@ def pmc_traffic(cfg, tp, batch, ctx, attn_bytes):
 
 
 @torch.inference_mode()
-def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6):
+def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6, pv_fp16=False):
     """Time nvh_prefill_varlen alone on `batch` sequences of `seq` tokens (q / k / v strided views of a fused projection
     output, as the model hands them over), cycling over distinct inputs (more than the 256 MiB Infinity Cache in total) between
     two HIP events on the launching stream."""
@@ -182,7 +182,7 @@ def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6):
 
     def call(x):
         q, k, v = x[:, :h * d].view(t, h, d), x[:, h * d:(h + kvh) * d].view(t, kvh, d), x[:, (h + kvh) * d:].view(t, kvh, d)
-        return ops.flash_attn_varlen_func(q, k, v, seq, cu, seq, cu)
+        return ops.flash_attn_varlen_func(q, k, v, seq, cu, seq, cu, pv_fp16=pv_fp16)      # (pv_fp16: the conversion of v is inside the timed call)
 
     for x in qkvs[:2]:
         call(x)
@@ -207,7 +207,8 @@ def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6):
     nbytes = t * (2 * h + 2 * kvh) * d * 2                              # q in, o out, k and v in
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e3), flops / (MFMA_PEAK_TFLOPS * 1e6)     # us at the two peaks
     bound = "hbm" if t_hbm >= t_mfma else "mfma"
-    return {"workload": f"{batch} sequences x {seq} tokens, H/KVH/D = {h}/{kvh}/{d}", "us_per_launch": round(us, 2),
+    return {"workload": f"{batch} sequences x {seq} tokens, H/KVH/D = {h}/{kvh}/{d}" + (" — OPT-IN fp16 P V (v converted inside the timed call; P rounded to fp16: "
+                        "4.5e-4 abs on the reference goldens instead of 6e-6; not the default, not the parity-pinned path)" if pv_fp16 else ""), "us_per_launch": round(us, 2),
             "us_per_launch_inputs_in_infinity_cache": round(us_warm, 2), "flops_per_launch": int(flops),
             "bytes_per_launch": int(nbytes), "achieved_TFLOPs": round(flops / us / 1e6, 1), "achieved_GBps": round(nbytes / us / 1e3, 1),
             "bound": bound, "us_at_bound": round(max(t_hbm, t_mfma), 2), "frac": round(max(t_hbm, t_mfma) / us, 4),
@@ -408,7 +409,8 @@ def main():
     if args.model == "Qwen2-0.5B" or args.prefill_leg:
         del sess
         torch.cuda.empty_cache()
-        prefill = {"config5_half": prefill_leg(cfg, tp, 128, 128), "s1024": prefill_leg(cfg, tp, 16, 1024, buffers=8, iters=4)}
+        prefill = {"config5_half": prefill_leg(cfg, tp, 128, 128), "s1024": prefill_leg(cfg, tp, 16, 1024, buffers=8, iters=4),
+                   "s1024_optin_fp16_pv": prefill_leg(cfg, tp, 16, 1024, buffers=8, iters=4, pv_fp16=True)}
     sweep = None
     if args.model == "Qwen2-0.5B" and world == 1 and not args.no_sweep:
         sweep = attention_sweep(cfg)

@@ -173,9 +173,12 @@ int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
  *   kernel       NVH_PREFILL_AUTO, NVH_PREFILL_TILED (64-row query tiles, K/V tiles double-buffered through LDS) or
  *                NVH_PREFILL_SHORT (one workgroup per (sequence, kv head), K/V resident in LDS: needs max_seqlen_q <=
  *                max_seqlen_k <= 128 and block_tables == NULL, otherwise an error)
+ *                NVH_PREFILL_TILED_F16V (a MEASUREMENT variant, not a drop-in: block_tables must be NULL): `v` holds the values as IEEE fp16 rows,
+ *                converted by the caller (same layout and strides); P is rounded to fp16 and P V runs as one fp16 MFMA per operand pair instead
+ *                of the bf16 hi + lo pair.  Error 4.5e-4 on the reference goldens (hi + lo: 6e-6), |v| <= 65504 required; DESIGN.md section 12.2
  *   short_waves  waves per workgroup of the short-sequence kernel: 0 = auto, 8 or 16
  */
-enum { NVH_PREFILL_AUTO = 0, NVH_PREFILL_TILED = 1, NVH_PREFILL_SHORT = 2 };
+enum { NVH_PREFILL_AUTO = 0, NVH_PREFILL_TILED = 1, NVH_PREFILL_SHORT = 2, NVH_PREFILL_TILED_F16V = 3 };
 int nvh_prefill_varlen_variant(int kernel, int short_waves, void* out, const void* q, const void* k, const void* v,
                                const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
                                const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,

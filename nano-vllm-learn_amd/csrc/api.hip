@@ -235,7 +235,7 @@ static int prefill_varlen_impl(int kernel, int short_waves, void* out, const voi
                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                        int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream) {
     if (batch == 0 || max_seqlen_q == 0) return 0;
-    if (kernel < 0 || kernel > 2 || (short_waves != 0 && short_waves != 8 && short_waves != 16)) {
+    if (kernel < 0 || kernel > 3 || (kernel == 3 && block_tables) || (short_waves != 0 && short_waves != 8 && short_waves != 16)) {
         set_error("prefill_varlen: kernel %d / short_waves %d not supported", kernel, short_waves);
         return NVH_E_SHAPE;
     }

@@ -107,7 +107,11 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 #endif
 }
 
-template <int D, bool PAGED, int QT>
+// F16V (measurement variant, NVH_PREFILL_TILED_F16V of nvh_prefill_varlen_variant): `v` holds fp16 rows (the caller converted them; same layout
+// and strides), P is rounded to fp16 and P V is ONE v_mfma_f32_16x16x32_f16 per operand pair — no lo half.  Everything else is the same code.
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int D, bool PAGED, int QT, bool F16V = false>
 __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a) {
     constexpr int BM = 64 * QT;                      // query rows per workgroup (4 waves x QT x 16)
     constexpr int ROWB = D * 2;                      // LDS row, bytes
@@ -348,6 +352,7 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
 #pragma unroll
             for (int hh = 0; hh < BN / 32; ++hh) {
                 bf16x8 p_hi[QT], p_lo[QT];
+                f16x8 p16[QT];
 #pragma unroll
                 for (int qs = 0; qs < QT; ++qs) {
                     // five VALU instructions per element PAIR: pack hi, two unpacks, one packed (exact) subtract, pack lo
@@ -355,14 +360,22 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const f32x2 pv = {sT[qs][2 * hh + (j >> 1)][2 * (j & 1)], sT[qs][2 * hh + (j >> 1)][2 * (j & 1) + 1]};
-                        const uint32_t hp = cvt_pk_bf16(pv[0], pv[1]);
-                        const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
-                        const f32x2 lo = pv - hf;
-                        hraw[j] = hp;
-                        lraw[j] = cvt_pk_bf16(lo[0], lo[1]);
+                        if constexpr (F16V) {
+                            hraw[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pv, f16x2v));   // v_cvt_pk_f16_f32 (round to nearest even)
+                        } else {
+                            const uint32_t hp = cvt_pk_bf16(pv[0], pv[1]);
+                            const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+                            const f32x2 lo = pv - hf;
+                            hraw[j] = hp;
+                            lraw[j] = cvt_pk_bf16(lo[0], lo[1]);
+                        }
                     }
-                    p_hi[qs] = *reinterpret_cast<const bf16x8*>(&hraw);
-                    p_lo[qs] = *reinterpret_cast<const bf16x8*>(&lraw);
+                    if constexpr (F16V) {
+                        p16[qs] = __builtin_bit_cast(f16x8, hraw);
+                    } else {
+                        p_hi[qs] = *reinterpret_cast<const bf16x8*>(&hraw);
+                        p_lo[qs] = *reinterpret_cast<const bf16x8*>(&lraw);
+                    }
                 }
                 u32x2 vlo[DT], vhi[DT];
                 if (hh == 0) {
@@ -380,6 +393,14 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (F16V) {
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        const u32x4 raw = {vlo[t][0], vlo[t][1], vhi[t][0], vhi[t][1]};
+#pragma unroll
+                        for (int qs = 0; qs < QT; ++qs) o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, raw), p16[qs], o[qs][t], 0, 0, 0);
+                    }
+                } else {
                 bf16x8 vf[DT];
 #pragma unroll
                 for (int t = 0; t < DT; ++t) {
@@ -395,6 +416,7 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 for (int t = 0; t < DT; ++t)
 #pragma unroll
                     for (int qs = 0; qs < QT; ++qs) o[qs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[t], p_lo[qs], o[qs][t], 0, 0, 0);
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // this wave's LDS reads of buffer `buf` are done
@@ -669,6 +691,10 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
 template <int D, int QT>
 int launch_q(const PrefillArgs& a, hipStream_t stream) {
     dim3 grid(a.h, a.batch, (a.max_seqlen_q + 64 * QT - 1) / (64 * QT));
+    if (a.kernel == 3) {                                         // NVH_PREFILL_TILED_F16V: v holds fp16 rows (measurement variant; never paged)
+        hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT, true>), grid, dim3(256), 0, stream, a);
+        return check_launch("prefill_varlen_f16v");
+    }
     if (a.block_tables) hipLaunchKernelGGL((prefill_varlen_kernel<D, true, QT>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT>), grid, dim3(256), 0, stream, a);
     return check_launch("prefill_varlen");
@@ -678,7 +704,7 @@ int launch_q(const PrefillArgs& a, hipStream_t stream) {
 template <int D>
 int launch_short(const PrefillArgs& a, hipStream_t stream, bool& taken) {
     taken = false;
-    const int mode = a.kernel == 1 ? 0 : a.kernel == 2 ? 2 : 1;
+    const int mode = (a.kernel == 1 || a.kernel == 3) ? 0 : a.kernel == 2 ? 2 : 1;
     const int max_keys = 128;                                    // (256 keys with four resident tiles measured slower than the tiled kernel)
     if (mode == 0 || a.block_tables || a.max_seqlen_k > max_keys || a.max_seqlen_q > a.max_seqlen_k) return 0;
     if (mode != 2 && a.batch * a.kvh < 128) return 0;            // few sequences: the tiled kernel spreads heads and q-tiles over the CUs

@@ -31,7 +31,7 @@ class LinearDesc(ctypes.Structure):
 
 
 EPI_NONE, EPI_SILU_MUL, EPI_RESIDUAL_ADD, EPI_ROPE_STORE = 0, 1, 2, 3
-PREFILL_KERNELS = {"auto": 0, "tiled": 1, "short": 2}                         # NVH_PREFILL_* (nvh_prefill_varlen_variant)
+PREFILL_KERNELS = {"auto": 0, "tiled": 1, "short": 2, "tiled_f16v": 3}                         # NVH_PREFILL_* (nvh_prefill_varlen_variant)
 DECODE_VARIANTS = {"chunked": 0, "split_mfma": 1, "split_valu": 2, "chunked_p128": 3, "chunked_p256": 4, "chunked_p64": 5}      # NVH_DECODE_* (nvh_paged_decode_variant)
 
 _c_i32p = ctypes.c_void_p

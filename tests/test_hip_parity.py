@@ -238,6 +238,31 @@ def test_prefill_golden(ops, golden, name):
     check_close(o32.cpu().numpy(), o16.float().cpu().numpy(), g["expected"], name)
 
 
+@pytest.mark.parametrize("name", PREFILL)
+def test_prefill_f16v_measurement_variant_golden(ops, golden, name):
+    """NVH_PREFILL_TILED_F16V (P rounded to fp16, V handed over as fp16, one MFMA per operand pair): a measurement variant, held to the
+    same 1e-3 bar on the reference goldens (expected error 4.5e-4, profiles/r03_prefill_instruction_census.txt) and, on a long sequence
+    that takes the two-sub-tile shape, against the shipped kernel."""
+    g = golden(name)
+    q, k, v = dev_bf16(g["q"]), dev_bf16(g["k"]), dev_bf16(g["v"])
+    cu = dev_i32(g["cu_seqlens"])
+    mx = int(np.diff(g["cu_seqlens"]).max())
+    o32 = ops.flash_attn_varlen_func(q, k, v.to(torch.float16), mx, cu, mx, cu, out_dtype=torch.float32, kernel="tiled_f16v")
+    torch.cuda.synchronize()
+    err = np.abs(o32.cpu().numpy() - g["expected"]).max()
+    assert 2e-5 < err <= ATOL, f"{name}: fp16-P variant max abs err {err:.3e}"      # (clearly not the hi + lo kernel, and inside the bar)
+    H, KVH, D = q.shape[1], k.shape[1], q.shape[2]
+    gen = torch.Generator().manual_seed(11)
+    S = 2304                                                     # two 16-row sub-tiles per wave at both head dims
+    qkv = torch.randn(S, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+    ql, kl, vl = qkv[:, :H * D].view(S, H, D), qkv[:, H * D:(H + KVH) * D].view(S, KVH, D), qkv[:, (H + KVH) * D:].view(S, KVH, D)
+    cul = dev_i32(np.array([0, S], np.int32))
+    a = ops.flash_attn_varlen_func(ql, kl, vl.to(torch.float16), S, cul, S, cul, out_dtype=torch.float32, kernel="tiled_f16v")
+    b = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, kernel="tiled")
+    torch.cuda.synchronize()
+    assert (a - b).abs().max().item() <= ATOL
+
+
 @pytest.mark.parametrize("H,KVH,D,lens", [
     (14, 2, 64, [1024, 1000, 17, 64, 65]),
     (16, 8, 128, [300, 129]),
@@ -777,3 +802,29 @@ def test_config1_shape_bs1_in512_out512(ops):
             e = O.paged_decode(new[step:step + 1, :H * D].view(1, H, D).float().numpy(), kc_ref, vc_ref, np.array([ctx], np.int32), bt)
             check_close(d32.cpu().numpy(), d16.float().cpu().numpy(), e, f"config 1 shape, decode at ctx {ctx}")
     assert np.array_equal(kc.float().cpu().numpy(), kc_ref) and np.array_equal(vc.float().cpu().numpy(), vc_ref)
+
+
+@pytest.mark.gpu
+def test_attention_module_opt_in_fp16_pv_prefill():
+    """Attention(prefill_pv_fp16=True): prefill of sequences with >= 1024 keys converts v to fp16 and runs P V on fp16 operands; shorter
+    batches and prefix-cached prefill keep the default form.  Against the oracle at the 1e-3 bar (N(0,1) inputs), and against the default module."""
+    from nanovllm_hip import reset_context, set_context
+    from nanovllm_hip.layers.attention_hip import Attention
+    H, KVH, D = 14, 2, 64
+    outs = {}
+    for lens in ([1100, 37], [200, 90]):
+        T = sum(lens)
+        gen = torch.Generator().manual_seed(T)
+        qkv = torch.randn(T, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+        q, k, v = qkv.split([H * D, KVH * D, KVH * D], dim=-1)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        exp = O.prefill_varlen(q.float().cpu().view(T, H, D).numpy(), k.float().cpu().view(T, KVH, D).numpy(), v.float().cpu().view(T, KVH, D).numpy(), cu, cu)
+        for opt in (False, True):
+            attn = Attention(H, D, D ** -0.5, KVH, prefill_pv_fp16=opt)
+            set_context(True, dev_i32(cu), dev_i32(cu), max(lens), max(lens), None, None, None)
+            o = attn(q, k, v).float().cpu().view(T, H, D).numpy()
+            reset_context()
+            assert (np.abs(o - exp) <= ATOL + BF16_ULP * np.abs(exp)).all()
+            outs[tuple(lens), opt] = o
+    assert not np.array_equal(outs[(1100, 37), True], outs[(1100, 37), False])       # the long batch took the fp16 form
+    assert np.array_equal(outs[(200, 90), True], outs[(200, 90), False])             # the short one did not
