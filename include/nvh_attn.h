@@ -186,6 +186,10 @@ int nvh_prefill_varlen_variant(int kernel, int short_waves, void* out, const voi
                                int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                                int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream);
 
+/* Helper of the opt-in NVH_PREFILL_TILED_F16V form: bf16 rows [n_rows, row_elems] (row strides in elements) -> IEEE fp16 rows, exact for |x| <= 65504
+ * (larger magnitudes become +-inf: the caller must know its V stays in range).  16-byte aligned rows, row_elems % 8 == 0. */
+int nvh_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, int64_t in_row_stride, int64_t out_row_stride, void* stream);
+
 /*
  * "Next" row: the step immediately before attention, fused into one launch.
  * (optional per-head RMSNorm ->) neox RoPE on q and k IN PLACE inside the fused qkv projection output, then

@@ -299,6 +299,15 @@ int nvh_prefill_varlen_variant(int kernel, int short_waves, void* out, const voi
                                block_size, max_blocks, q_row_stride, k_row_stride, v_row_stride, bt_row_stride, scale, dtype, out_dtype, stream);
 }
 
+int nvh_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, int64_t in_row_stride, int64_t out_row_stride, void* stream) {
+    if (n_rows == 0) return 0;
+    if (!out || !in) { set_error("bf16_rows_to_f16: null pointer"); return NVH_E_NULL; }
+    if (n_rows < 0 || row_elems <= 0 || row_elems % 8) { set_error("bf16_rows_to_f16: n_rows %d, row_elems %d (a positive multiple of 8)", n_rows, row_elems); return NVH_E_SHAPE; }
+    if (in_row_stride % 8 || out_row_stride % 8 || in_row_stride < row_elems || out_row_stride < row_elems) { set_error("bf16_rows_to_f16: bad row strides"); return NVH_E_STRIDE; }
+    if (!aligned16(out) || !aligned16(in)) { set_error("bf16_rows_to_f16: pointers must be 16-byte aligned"); return NVH_E_ALIGN; }
+    return launch_bf16_rows_to_f16(out, in, n_rows, row_elems, in_row_stride, out_row_stride, (hipStream_t)stream);
+}
+
 int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,
                    const void* q_norm_w, const void* k_norm_w, float eps,
                    void* k_cache, void* v_cache, const int32_t* slot_mapping,

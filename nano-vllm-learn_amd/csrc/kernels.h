@@ -10,6 +10,8 @@ int launch_store_kvcache(const void* k, const void* v, void* k_cache, void* v_ca
                          const int32_t* slot_mapping, int n_tokens, int kvh, int hd,
                          int64_t k_row_stride, int64_t v_row_stride, hipStream_t stream);
 
+int launch_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, int64_t in_row_stride, int64_t out_row_stride, hipStream_t stream);
+
 struct DecodeArgs {
     void* out;                   // [B, H, D] bf16 or f32
     const uint16_t* q;           // [B, H, D] bf16, row stride q_row_stride

@@ -192,8 +192,12 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
     (NVH_PREFILL_TILED_F16V): 1.2-1.4x faster at S >= 1024, P rounded to 11 bits — error <= 2^-12 * max|v| (4.5e-4 on the reference goldens,
     against 6e-6 for the default bf16 hi + lo form) and |v| <= 65504 required; DESIGN.md section 12.2."""
     if pv_fp16 and block_table is None and kernel is None:
-        v = v.to(torch.float16)
-        kernel = "tiled_f16v"
+        _require_gpu_bf16(v=v)
+        assert v.dim() == 3 and v.stride(-1) == 1 and v.stride(1) == v.shape[2]
+        v16 = torch.empty(v.shape, dtype=torch.float16, device=v.device)
+        _lib.check(_lib.load().nvh_bf16_rows_to_f16(v16.data_ptr(), v.data_ptr(), v.shape[0], v.shape[1] * v.shape[2], v.stride(0), v16.stride(0), _stream()),
+                   "nvh_bf16_rows_to_f16")
+        v, kernel = v16, "tiled_f16v"
     if not causal:
         raise NotImplementedError("the reference only ever calls this with causal=True (attention.py:96)")
     tq, h, hd = q.shape

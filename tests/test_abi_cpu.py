@@ -75,10 +75,17 @@ def test_argument_validation_without_gpu(lib):
     assert lib.nvh_greedy_advance_candidates_embed(p, p, 8, 64, 0, p, p, p, p, p, 4, 256, p, 4, p, None, 0, 0, None, 0, None, 0, None) == 0   # zero rows
     # the variant entry points validate their selectors
     dec = (p, p, p, p, p, p, 1, 14, 2, 64, 256, 4, 896, 4, 0.1, 0, 0, p, 1 << 20, None)
-    assert lib.nvh_paged_decode_variant(5, 0, 0, *dec) == -2 and lib.nvh_paged_decode_variant(0, 5, 0, *dec) == -2
+    assert lib.nvh_paged_decode_variant(6, 0, 0, *dec) == -2 and lib.nvh_paged_decode_variant(0, 5, 0, *dec) == -2
     assert lib.nvh_paged_decode_variant(2, 0, 0, p, p, p, p, p, p, 1, 16, 1, 64, 256, 4, 1024, 4, 0.1, 0, 0, p, 1 << 20, None) == -2   # VALU form: G <= 8
     pre = (p, p, p, p, p, p, None, 2, 16, 16, 14, 2, 64, 0, 0, 896, 128, 128, 0, 0.1, 0, 0, None)
-    assert lib.nvh_prefill_varlen_variant(3, 0, *pre) == -2 and lib.nvh_prefill_varlen_variant(2, 4, *pre) == -2
+    assert lib.nvh_prefill_varlen_variant(4, 0, *pre) == -2 and lib.nvh_prefill_varlen_variant(2, 4, *pre) == -2
+    paged = (p, p, p, p, p, p, p, 2, 16, 16, 14, 2, 64, 256, 4, 896, 128, 128, 4, 0.1, 0, 0, None)
+    assert lib.nvh_prefill_varlen_variant(3, 0, *paged) == -2                       # the fp16-V measurement variant never reads a paged cache
+    # the fused front of a decode layer and the fp16 row conversion: argument errors before any launch
+    assert lib.nvh_qkv_rope_attend(None, p, None, p, p, 256, 4, 4, 0.1, 0, p, 1 << 20, None) == -5
+    assert lib.nvh_qkv_rope_attend_status(None, None) == -5
+    assert lib.nvh_bf16_rows_to_f16(p, p, 4, 100, 128, 128, None) == -2 and lib.nvh_bf16_rows_to_f16(p, p, 4, 128, 100, 128, None) == -3
+    assert lib.nvh_bf16_rows_to_f16(None, None, 0, 128, 128, 128, None) == 0
 
 
 def test_ops_refuse_cpu_tensors():
