@@ -337,66 +337,86 @@ def main():
     window = max(args.steps, args.input_len) if not args.no_full_window else args.steps      # bench_my's decode phase: out = in tokens
     total_len = args.input_len + window + args.warmup + 2
     blocks_per_seq = (total_len + bs - 1) // bs
-    engine = LLMEngine(cfg, num_kvcache_blocks=args.batch * blocks_per_seq + 8, max_model_len=max(4096, total_len),
-                       enforce_eager=args.eager, seed=0, warmup=True)     # start-up warmup as the reference (model_runner.py:107-121)
+    def run_decode():
+        """Engine start-up, prefill, W untimed + K timed decode steps and the full-window replay.  A one-shot all-reduce that marked a
+        failed call (a peer that did not arrive within its bounded wait: never yet seen, but xGMI has never run this kernel either) raises
+        on EVERY rank at the first synchronisation behind it."""
+        engine = LLMEngine(cfg, num_kvcache_blocks=args.batch * blocks_per_seq + 8, max_model_len=max(4096, total_len),
+                           enforce_eager=args.eager, seed=0, warmup=True)     # start-up warmup as the reference (model_runner.py:107-121)
 
-    seed(0)
-    prompts = [[randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.batch)]
-    seqs = [Sequence(p, max_tokens=window + 1) for p in prompts]
+        seed(0)
+        prompts = [[randint(0, 10000) for _ in range(args.input_len)] for _ in range(args.batch)]
+        seqs = [Sequence(p, max_tokens=window + 1) for p in prompts]
 
-    # ---- prefill (outside the timed decode region; timed on its own)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    engine.prefill(seqs, reserve_tokens=window + args.warmup + 2)
-    torch.cuda.synchronize()
-    prefill_s = time.perf_counter() - t0
-    ctx0 = len(seqs[0])                                               # input_len + 1: first decode step's context
+        # ---- prefill (outside the timed decode region; timed on its own)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        engine.prefill(seqs, reserve_tokens=window + args.warmup + 2)
+        torch.cuda.synchronize()
+        prefill_s = time.perf_counter() - t0
+        ctx0 = len(seqs[0])                                               # input_len + 1: first decode step's context
 
-    # ---- decode: W untimed steps, rewind to the same context, then exactly K timed steps
-    sess = engine.runner.decode_session(seqs, window + args.warmup + 1, use_graph=not args.eager)
-    state0 = sess.state()
-    sess.step(args.warmup)
-    sess.rewind(state0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sess.step(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    graph_mode = sess.graph is not None
-    if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # ---- decode: W untimed steps, rewind to the same context, then exactly K timed steps
+        sess = engine.runner.decode_session(seqs, window + args.warmup + 1, use_graph=not args.eager)
+        state0 = sess.state()
+        sess.step(args.warmup)
+        sess.rewind(state0)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sess.step(args.steps)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        graph_mode = sess.graph is not None
+        if world > 1:
+            t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        tok_s = args.batch * args.steps / elapsed
+        engine.runner.raise_if_device_failed()
+
+        # ---- the whole bench_my window (contexts in+1 -> 2 in), once more from the same start: what bench_my.py:27-40 reports for in = out
+        full = None
+        if not args.no_full_window:
+            if window == args.steps:
+                full_elapsed = elapsed
+            else:
+                sess.rewind(state0)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                sess.step(window)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                full_elapsed = time.perf_counter() - t0
+                if world > 1:
+                    t = torch.tensor([full_elapsed], device="cuda", dtype=torch.float64)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    full_elapsed = float(t.item())
+                engine.runner.raise_if_device_failed()
+            full = (window, full_elapsed)
+        return engine, seqs, prefill_s, ctx0, sess, elapsed, graph_mode, full
+
+    oneshot_note = None
+    try:
+        engine, seqs, prefill_s, ctx0, sess, elapsed, graph_mode, full = run_decode()
+    except RuntimeError as e:
+        if world == 1 or "one-shot all-reduce failed" not in str(e):
+            raise
+        # every rank is here (the check is a collective): measure on RCCL instead and say so in the line
+        oneshot_note = f"the one-shot all-reduce was abandoned after: {e}"
+        os.environ["NVH_ALLREDUCE"] = "rccl"
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        engine, seqs, prefill_s, ctx0, sess, elapsed, graph_mode, full = run_decode()
     tok_s = args.batch * args.steps / elapsed
-    engine.runner.raise_if_device_failed()
-
-    # ---- the whole bench_my window (contexts in+1 -> 2 in), once more from the same start: what bench_my.py:27-40 reports for in = out
-    full = None
-    if not args.no_full_window:
-        if window == args.steps:
-            full_elapsed = elapsed
-        else:
-            sess.rewind(state0)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t0 = time.perf_counter()
-            sess.step(window)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            full_elapsed = time.perf_counter() - t0
-            if world > 1:
-                t = torch.tensor([full_elapsed], device="cuda", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                full_elapsed = float(t.item())
-        full = (window, full_elapsed)
 
     # ---- roofline leg: the attention op alone at the mean context of the timed window
     mean_ctx = ctx0 + (args.steps - 1) // 2
@@ -441,7 +461,8 @@ def main():
                                        + ("one-shot over IPC-mapped peer buffers with the residual add fused in (nvh_allreduce_oneshot), inside the HIP graph"
                                           if engine.runner.comm is not None else "RCCL ring through torch.distributed") + f" [{tp_choice}]") if world > 1 else "none (single GPU)"),
                        "collective_detail": ({"path": "oneshot" if engine.runner.comm is not None else "torch.distributed",
-                                              "startup_measurement_us": nvh_dist.last_measurement, "failed_epoch": failed_epoch} if world > 1 else None),
+                                              "startup_measurement_us": nvh_dist.last_measurement, "failed_epoch": failed_epoch,
+                                              "note": oneshot_note} if world > 1 else None),
                        "heads_per_rank_q0_qn_kv0_kvn": shapes},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_note,
