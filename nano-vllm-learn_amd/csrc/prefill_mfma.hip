@@ -730,7 +730,10 @@ int launch_d(const PrefillArgs& a, hipStream_t stream) {
     const int rc = launch_short<D>(a, stream, taken);
     if (taken) return rc;
     if (a.kernel == 2) { set_error("prefill_varlen: the short-sequence kernel needs max_seqlen_q <= max_seqlen_k <= 128 and no block table"); return -2; }
-    const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= 2048;
+#ifndef NVH_PREFILL_QT2_FROM
+#define NVH_PREFILL_QT2_FROM 2048            // D = 64: two 16-row sub-tiles per wave from this many query rows on (A/B builds change it)
+#endif
+    const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= NVH_PREFILL_QT2_FROM;
     return two ? launch_q<D, 2>(a, stream) : launch_q<D, 1>(a, stream);
 }
 
