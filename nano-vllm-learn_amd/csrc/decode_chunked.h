@@ -799,6 +799,11 @@ __device__ __forceinline__ void decode_chunked_body(
                             ml[i] = ld16_sc1(rb, r + 4 * (g * (D + 4) + D));
                             av[i] = ld16_sc1(rb, r + 16 * (it + g));
                         }
+                        // every load of the batch is ISSUED here, before any is consumed: left alone, hipcc sank the last load of an 8-wide batch
+                        // into the `c0 + i < live_chunks` block that uses it — behind the wait for the other fifteen, a second memory-side round
+                        // trip (0.6 us) in the last arriver of every pair split over 5-8 workgroups (stamped: 1.24 us for this step at 7/1/128)
+#pragma unroll
+                        for (int i = 0; i < CB; ++i) asm volatile("" : "+v"(ml[i]), "+v"(av[i]));
                         float Mc = M;
 #pragma unroll
                         for (int i = 0; i < CB; ++i)

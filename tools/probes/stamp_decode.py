@@ -9,7 +9,7 @@ CSRC = os.path.join(ROOT, "nano-vllm-learn_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "probes", "libnvh_attn_stamps.so")
 
 def build(tail=False):
-    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip", "allreduce_oneshot.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("api.hip", "store_kvcache.hip", "paged_decode.hip", "prefill_mfma.hip", "rope_store.hip", "layer_ops.hip", "skinny_gemm.hip", "linear_stream.hip", "allreduce_oneshot.hip", "qkv_attend.hip")]
     subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DNVH_STAMPS", *(["-DNVH_STAMPS_TAIL"] if tail else []), "-ffp-contract=off", "-mllvm", "-amdgpu-mfma-vgpr-form",
                     "-mllvm", "-amdgpu-kernarg-preload-count=14",
                     "-Wno-unused-command-line-argument", *srcs, "-o", OUT], check=True)
