@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NVH_VERSION 204          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch; 203: NVH_DECODE_CHUNKED_P256; 204: nvh_qkv_rope_attend */
+#define NVH_VERSION 205          /* major*100 + minor; 201: nvh_allreduce_status; 202: nvh_linear_desc.prefetch; 203: NVH_DECODE_CHUNKED_P256; 204: nvh_qkv_rope_attend; 205: nvh_prefill_varlen_pv16 */
 
 /* dtype codes */
 #define NVH_BF16 0
@@ -186,9 +186,31 @@ int nvh_prefill_varlen_variant(int kernel, int short_waves, void* out, const voi
                                int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                                int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream);
 
-/* Helper of the opt-in NVH_PREFILL_TILED_F16V form: bf16 rows [n_rows, row_elems] (row strides in elements) -> IEEE fp16 rows, exact for |x| <= 65504
- * (larger magnitudes become +-inf: the caller must know its V stays in range).  16-byte aligned rows, row_elems % 8 == 0. */
+/* Helper of the NVH_PREFILL_TILED_F16V measurement form: bf16 rows [n_rows, row_elems] (row strides in elements) -> IEEE fp16 rows, exact for
+ * 2^-24 <= |x| <= 65504 (larger finite magnitudes are clamped: the caller must know its V stays in range — nvh_prefill_varlen_pv16 below checks it).
+ * 16-byte aligned rows, row_elems % 8 == 0. */
 int nvh_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, int64_t in_row_stride, int64_t out_row_stride, void* stream);
+
+/*
+ * nvh_prefill_varlen (block_tables == NULL) with P V on the fp16 matrix pipe — same arguments, same result within the parity bar, 1.2-1.4x faster from 1024
+ * keys per sequence on (the tile loop is bound by vector-instruction issue and the bf16 hi + lo split of P is a third of it).
+ * Replaces: flash_attn_varlen_func, nanovllm/layers/attention.py:93-96 (whose own P is a single bf16: 8 significant bits against the 11 used here).
+ * Two launches, no host read, nothing to clear, capture-safe: V is converted to fp16 rows in `scratch` (exact for 2^-24 <= |v| <= 65504; smaller magnitudes
+ * become 0) and every 64-row group gets a range flag (set when a finite value does not fit fp16); the attention kernel ORs the flags that cover a
+ * sequence's rows and runs fp16 P x fp16 V for it, or — a flag set, or the sequence reaching past total_k — the exact bf16 hi + lo form on the caller's own
+ * V rows, i.e. exactly nvh_prefill_varlen for that sequence.  Numerics of the fp16 form: P in [0, 1] rounded to 11 significant bits, products accumulated
+ * in fp32: |error| <= 2^-12 * max|v| per output element, 4.5e-4 on the reference's golden vectors (N(0,1) values; hi + lo: 6e-6; bf16 OUTPUT rounding
+ * alone: 2^-9 * |o|).  Shapes the short-sequence kernel takes (max_seqlen_k <= 128, >= 128 (sequence, kv head) pairs) run that kernel unchanged
+ * (hi + lo; scratch untouched).
+ *   total_k        rows of k / v (= cu_seqlens_k[batch] on the host)
+ *   scratch        device memory of at least nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd) bytes (flags: 4 * ceil(total_k / 64) rounded up to 256, then
+ *                  total_k*kvh*hd*2), 16-byte aligned, owned by the caller, not shared with a call in flight on another stream
+ */
+size_t nvh_prefill_pv16_scratch_bytes(int total_k, int kvh, int hd);
+int nvh_prefill_varlen_pv16(void* out, const void* q, const void* k, const void* v,
+                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch, int max_seqlen_q, int max_seqlen_k, int total_k,
+                            int h, int kvh, int hd, int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                            float scale, int dtype, int out_dtype, void* scratch, size_t scratch_bytes, void* stream);
 
 /*
  * "Next" row: the step immediately before attention, fused into one launch.

@@ -87,6 +87,8 @@ int nvh_store_kvcache(const void* k, const void* v, void* k_cache, void* v_cache
 static constexpr size_t kDecodeTicketBytes = 65536;       // 512 tickets, one per 128-byte line (pairs are split over chunks only when there are few of them)
 static constexpr size_t kDecodeSyncBytes = 8192;          // behind the tickets: the ready / done counters and the status word of nvh_qkv_rope_attend
 static constexpr size_t kDecodeHeaderBytes = kDecodeTicketBytes + kDecodeSyncBytes;
+// nvh_prefill_varlen_pv16 scratch: one int32 range flag per kPv16GroupRows rows (padded to 256 bytes), then the fp16 rows
+static size_t pv16_header_bytes(int total_k) { return ((size_t)((total_k + nvh::kPv16GroupRows - 1) / nvh::kPv16GroupRows) * 4 + 255) / 256 * 256; }
 
 static int decode_num_splits(int hd, int max_blocks, int block_size) {
     const int split = decode_split_tokens(hd);
@@ -233,7 +235,8 @@ static int prefill_varlen_impl(int kernel, int short_waves, void* out, const voi
                        const int32_t* block_tables, int batch, int max_seqlen_q, int max_seqlen_k,
                        int h, int kvh, int hd, int block_size, int max_blocks,
                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
-                       int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream) {
+                       int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream,
+                       int total_k = 0, void* pv16_scratch = nullptr, size_t pv16_scratch_bytes = 0) {
     if (batch == 0 || max_seqlen_q == 0) return 0;
     if (kernel < 0 || kernel > 3 || (kernel == 3 && block_tables) || (short_waves != 0 && short_waves != 8 && short_waves != 16)) {
         set_error("prefill_varlen: kernel %d / short_waves %d not supported", kernel, short_waves);
@@ -276,7 +279,40 @@ static int prefill_varlen_impl(int kernel, int short_waves, void* out, const voi
     a.out_f32 = out_dtype == NVH_F32;
     a.stamps = g_stamps;
     a.kernel = kernel; a.short_waves = short_waves;
+    if (pv16_scratch) {
+        // fp16 P V on an fp16 copy of V made here: [one range flag per 64 rows, padded to 256 bytes][total_k rows of kvh*hd fp16].  Two launches, no host
+        // read, nothing to clear: convert (every workgroup writes its group's flag), attend (a sequence with a flagged group falls back to `v` itself).
+        if (block_tables) { set_error("prefill_varlen_pv16: not with a block table (V is read from the cache)"); return NVH_E_SHAPE; }
+        if (total_k <= 0 || !aligned16(pv16_scratch) || pv16_scratch_bytes < nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd)) {
+            set_error("prefill_varlen_pv16: scratch of %zu bytes, %zu needed for %d rows (16-byte aligned)", pv16_scratch_bytes,
+                      nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd), total_k);
+            return NVH_E_WORKSPACE;
+        }
+        if (a.max_seqlen_k > 128 || a.max_seqlen_q > a.max_seqlen_k || a.batch * a.kvh < 128) {     // not the short-sequence kernel's shapes (it keeps hi + lo)
+            int32_t* flags = (int32_t*)pv16_scratch;
+            uint16_t* v16 = (uint16_t*)((char*)pv16_scratch + pv16_header_bytes(total_k));
+            rc = launch_bf16_rows_to_f16(v16, v, total_k, kvh * hd, v_row_stride, (int64_t)kvh * hd, flags, (hipStream_t)stream);
+            if (rc) return rc;
+            a.v16 = v16; a.v16_row_stride = (int64_t)kvh * hd; a.pv16_flags = flags; a.pv16_rows = total_k;
+            a.kernel = 1;                                        // the tiled kernel
+        }
+    }
     return launch_prefill_varlen(a, (hipStream_t)stream);
+}
+
+size_t nvh_prefill_pv16_scratch_bytes(int total_k, int kvh, int hd) {
+    if (total_k <= 0 || kvh <= 0 || hd <= 0) return 0;
+    return pv16_header_bytes(total_k) + (size_t)total_k * kvh * hd * 2;
+}
+
+int nvh_prefill_varlen_pv16(void* out, const void* q, const void* k, const void* v,
+                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch, int max_seqlen_q, int max_seqlen_k, int total_k,
+                            int h, int kvh, int hd, int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
+                            float scale, int dtype, int out_dtype, void* scratch, size_t scratch_bytes, void* stream) {
+    if (batch == 0 || max_seqlen_q == 0) return 0;
+    if (!scratch) { set_error("prefill_varlen_pv16: null scratch"); return NVH_E_NULL; }
+    return prefill_varlen_impl(0, 0, out, q, k, v, cu_seqlens_q, cu_seqlens_k, nullptr, batch, max_seqlen_q, max_seqlen_k, h, kvh, hd,
+                               0, 0, q_row_stride, k_row_stride, v_row_stride, 0, scale, dtype, out_dtype, stream, total_k, scratch, scratch_bytes);
 }
 
 int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,
@@ -305,7 +341,7 @@ int nvh_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, i
     if (n_rows < 0 || row_elems <= 0 || row_elems % 8) { set_error("bf16_rows_to_f16: n_rows %d, row_elems %d (a positive multiple of 8)", n_rows, row_elems); return NVH_E_SHAPE; }
     if (in_row_stride % 8 || out_row_stride % 8 || in_row_stride < row_elems || out_row_stride < row_elems) { set_error("bf16_rows_to_f16: bad row strides"); return NVH_E_STRIDE; }
     if (!aligned16(out) || !aligned16(in)) { set_error("bf16_rows_to_f16: pointers must be 16-byte aligned"); return NVH_E_ALIGN; }
-    return launch_bf16_rows_to_f16(out, in, n_rows, row_elems, in_row_stride, out_row_stride, (hipStream_t)stream);
+    return launch_bf16_rows_to_f16(out, in, n_rows, row_elems, in_row_stride, out_row_stride, nullptr, (hipStream_t)stream);
 }
 
 int nvh_rope_store(void* qkv, const int64_t* positions, const float* cos_sin,

@@ -10,7 +10,8 @@ int launch_store_kvcache(const void* k, const void* v, void* k_cache, void* v_ca
                          const int32_t* slot_mapping, int n_tokens, int kvh, int hd,
                          int64_t k_row_stride, int64_t v_row_stride, hipStream_t stream);
 
-int launch_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, int64_t in_row_stride, int64_t out_row_stride, hipStream_t stream);
+constexpr int kPv16GroupRows = 64;   // rows per range flag of the bf16 -> fp16 conversion (one conversion workgroup per group)
+int launch_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, int64_t in_row_stride, int64_t out_row_stride, int32_t* group_flags, hipStream_t stream);
 
 struct DecodeArgs {
     void* out;                   // [B, H, D] bf16 or f32
@@ -180,6 +181,10 @@ struct PrefillArgs {
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
     int kernel;                  // 0 auto, 1 tiled kernel only, 2 short-sequence kernel (error if the shape does not allow it)
     int short_waves;             // short-sequence kernel: 0 auto, 8 or 16 waves per workgroup
+    const uint16_t* v16 = nullptr;        // nvh_prefill_varlen_pv16: fp16 copy of the V rows [Tk, KVH, D] (row stride v16_row_stride) ...
+    int64_t v16_row_stride = 0;
+    int pv16_rows = 0;                    // rows converted (total_k of the call): a sequence reaching past them takes the exact form
+    const int32_t* pv16_flags = nullptr;  // ... and one word per kPv16GroupRows rows, non-zero where a value did not fit fp16 (that sequence uses `v`, hi + lo bf16 P)
 };
 int launch_prefill_varlen(const PrefillArgs& a, hipStream_t stream);
 

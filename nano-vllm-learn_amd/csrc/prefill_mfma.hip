@@ -111,26 +111,12 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
 // and strides), P is rounded to fp16 and P V is ONE v_mfma_f32_16x16x32_f16 per operand pair — no lo half.  Everything else is the same code.
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int D, bool PAGED, int QT, bool F16V = false>
-__global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a) {
-    constexpr int BM = 64 * QT;                      // query rows per workgroup (4 waves x QT x 16)
-    constexpr int ROWB = D * 2;                      // LDS row, bytes
-    constexpr int LPT = D / 8;                       // 16-byte chunks per row
-    constexpr int TPI = 64 / LPT;                    // rows per DMA instruction
-    constexpr int IMG = BN * ROWB;                   // one K (or V) image: 8 KiB (D=64) / 16 KiB (D=128)
-    constexpr int NI = IMG / 1024;                   // DMA instructions per image
-    constexpr int NIW = NI / 4;                      // ... per wave
-    constexpr int STEPS = D / 32;                    // k-steps of the QK^T contraction
-    constexpr int DT = D / 16;                       // 16-dim output tiles
-    constexpr int NT = BN / 16;                      // 16-key tiles of S^T per LDS tile
-    constexpr int WR = 16 * QT;                      // query rows per wave
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * IMG];     // [buffer][K | V]
-
-    // grid (H, B, q-tiles): workgroups are dispatched x-fastest, so the q-tile index is the SLOW dimension and runs backwards:
-    // under the causal mask tile t costs t+1 key tiles, and dispatching the heaviest tiles of every (sequence, head) first
-    // leaves the light ones for the tail (census in tools/probes/stamp_prefill.py: the old x = q-tile order spent the last
-    // 40 % of the launch draining a few heavy workgroups that had started late)
-    int qt = gridDim.z - 1 - blockIdx.z, head = blockIdx.x, b = blockIdx.y;
+// grid (H, B, q-tiles) -> this workgroup's (q-tile, head, sequence).  Workgroups are dispatched x-fastest, so the q-tile index is the SLOW dimension
+// and runs backwards: under the causal mask tile t costs t+1 key tiles, and dispatching the heaviest tiles of every (sequence, head) first leaves
+// the light ones for the tail (census in tools/probes/stamp_prefill.py: the old x = q-tile order spent the last 40 % of the launch draining a
+// few heavy workgroups that had started late)
+__device__ __forceinline__ void prefill_tile_of_block(const PrefillArgs& a, int& qt, int& head, int& b) {
+    qt = gridDim.z - 1 - blockIdx.z, head = blockIdx.x, b = blockIdx.y;
 #ifndef NVH_PREFILL_NO_XCD_MAP
     {
         // XCD-aware order (speed only; any mapping is correct): workgroups are dealt round-robin over the 8 XCDs, each with an L2 of its
@@ -149,11 +135,30 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         }
     }
 #endif
+}
+
+// One workgroup's tile: query rows qt * 64 * QT .. of (sequence b, head), all the keys they can see.
+// GUARD (nvh_prefill_varlen_pv16): `a.v` is the fp16 copy of V; the range flags of this sequence's rows are fetched FIRST, the first K image's DMA is
+// issued behind them, and only then are they looked at — so the check costs no memory latency of its own.  Returns false (nothing but that K image
+// touched) when a flag is set: the caller runs the exact body instead.
+template <int D, bool PAGED, int QT, bool F16V, bool GUARD = false>
+__device__ __forceinline__ bool prefill_varlen_body(const PrefillArgs& a, unsigned char* const lds, const int qt, const int head, const int b) {
+    constexpr int BM = 64 * QT;                      // query rows per workgroup (4 waves x QT x 16)
+    constexpr int ROWB = D * 2;                      // LDS row, bytes
+    constexpr int LPT = D / 8;                       // 16-byte chunks per row
+    constexpr int TPI = 64 / LPT;                    // rows per DMA instruction
+    constexpr int IMG = BN * ROWB;                   // one K (or V) image: 8 KiB (D=64) / 16 KiB (D=128)
+    constexpr int NI = IMG / 1024;                   // DMA instructions per image
+    constexpr int NIW = NI / 4;                      // ... per wave
+    constexpr int STEPS = D / 32;                    // k-steps of the QK^T contraction
+    constexpr int DT = D / 16;                       // 16-dim output tiles
+    constexpr int NT = BN / 16;                      // 16-key tiles of S^T per LDS tile
+    constexpr int WR = 16 * QT;                      // query rows per wave
     const int q_beg = a.cu_q[b], q_end = a.cu_q[b + 1];
     const int k_beg = a.cu_k[b], k_end = a.cu_k[b + 1];
     const int sq = q_end - q_beg, sk = k_end - k_beg;
     const int q0 = qt * BM;
-    if (q0 >= sq || sk <= 0) return;
+    if (q0 >= sq || sk <= 0) return true;
     const int kh = head / (a.h / a.kvh);
     const int shift = sk - sq;                       // bottom-right alignment: query r sees keys <= r + shift
 
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
         koff[j] = (uint32_t)(R * kstride + (dp ^ chunk_swz<LPT>(R)) * 8);
         voff[j] = (uint32_t)(R * vstride + (dp ^ chunk_swz_v<LPT>(R)) * 8);
     }
-    auto stage = [&](int tile, int buf) {
+    auto stage = [&](int tile, int buf, const bool do_k = true, const bool do_v = true) {
         unsigned char* kimg = lds + buf * 2 * IMG;
         unsigned char* vimg = kimg + IMG;
         const int kv0 = tile * BN;
@@ -220,14 +225,38 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 ko = (uint32_t)(Rc * kstride + (dp ^ chunk_swz<LPT>(R)) * 8);
                 vo = (uint32_t)(Rc * vstride + (dp ^ chunk_swz_v<LPT>(R)) * 8);
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko),
-                                             (__attribute__((address_space(3))) void*)(kimg + ins * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + vo),
-                                             (__attribute__((address_space(3))) void*)(vimg + ins * 1024), 16, 0, 0);
+            if (do_k) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + ko),
+                                                       (__attribute__((address_space(3))) void*)(kimg + ins * 1024), 16, 0, 0);
+            if (do_v) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + vo),
+                                                       (__attribute__((address_space(3))) void*)(vimg + ins * 1024), 16, 0, 0);
         }
     };
 
-    stage(0, 0);
+    if constexpr (GUARD) {
+        // one flag per kPv16GroupRows rows of V; lane l looks at groups g0 + l, + 64, + 128, + 192 (16384 rows: the largest prefill batch), a plain loop
+        // takes longer sequences.  The loads are inline asm so that no compiler-placed wait sits between them and the K image's DMA.
+        const int rows_ok = k_end < a.pv16_rows ? k_end : a.pv16_rows;
+        const int g0 = k_beg / kPv16GroupRows, g1 = (rows_ok + kPv16GroupRows - 1) / kPv16GroupRows;
+        const int last = g1 > g0 ? g1 - 1 : g0;
+        int fl[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int g = g0 + lane + 64 * i;
+            const int32_t* p = a.pv16_flags + (g < last ? g : last);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(fl[i]) : "v"(p) : "memory");
+        }
+        stage(0, 0, true, false);
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(fl[0]), "+v"(fl[1]), "+v"(fl[2]), "+v"(fl[3]) : "n"(NIW) : "memory");
+        bool bad = k_end > a.pv16_rows;              // (a caller whose total_k was short of cu_seqlens_k[batch]: no fp16 copy of those rows)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bad |= __builtin_amdgcn_ballot_w64(g0 + lane + 64 * i < g1 && fl[i] != 0) != 0;
+        for (int g = g0 + 256 + lane; __builtin_amdgcn_ballot_w64(g < g1) != 0; g += 64)
+            bad |= __builtin_amdgcn_ballot_w64(g < g1 && a.pv16_flags[g < g1 ? g : last] != 0) != 0;
+        if (bad) return false;
+        stage(0, 0, false, true);
+    } else {
+        stage(0, 0);
+    }
     // ---- Q fragments (B operand of S^T): Q[row][32*step + 8*lg .. +8]; plain loads issued BEHIND the first tile's DMA, so that a workgroup
     // pays one memory latency at its start, not two in a row (the counted wait of the first tile body leaves only tile 1's DMA in flight:
     // vector-memory operations complete in order, so tile 0 and these loads have landed by then)
@@ -449,6 +478,39 @@ __global__ __launch_bounds__(256) void prefill_varlen_kernel(const PrefillArgs a
                 *reinterpret_cast<u32x2*>(reinterpret_cast<uint16_t*>(a.out) + orow + d0) = pk;
             }
         }
+    }
+    return true;
+}
+
+// PV: 0 = P as hi + lo bf16 against the caller's bf16 V (exact to 6e-6; the form every other path of this file uses), 1 = fp16 P against fp16 V rows
+// handed over in `v` (NVH_PREFILL_TILED_F16V, measurement variant), 2 = nvh_prefill_varlen_pv16: fp16 P against the fp16 copy of V in `v16` UNLESS the
+// conversion launch ahead of this one flagged a 64-row group of THIS sequence's V rows (a finite |v| > 65504 does not fit fp16): then the hi + lo form
+// on the caller's own rows.  Every conversion workgroup writes its group's flag unconditionally (nothing to clear); a wave ORs the flags that cover its
+// sequence behind the first K image's DMA (GUARD above); both bodies are instantiations of the same code.
+template <int D, bool PAGED, int QT, int PV = 0>
+__global__ __launch_bounds__(256)
+__attribute__((amdgpu_waves_per_eu(PV == 2 && D == 64 && QT == 2 ? 4 : 1)))         // (the guarded kernel at the fp16 body's 128 registers: hipcc gives it 134 otherwise)
+void prefill_varlen_kernel(const PrefillArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * BN * D * 2];     // [buffer][K | V]
+    int qt, head, b;
+    prefill_tile_of_block(a, qt, head, b);
+    if constexpr (PV == 2) {
+        static_assert(!PAGED, "the fp16 copy of V is made from packed rows");
+        PrefillArgs f = a;
+        f.v = a.v16;
+        f.v_row_stride = a.v16_row_stride;
+        if (!prefill_varlen_body<D, false, QT, true, true>(f, lds, qt, head, b)) {
+            // the fall-back runs the one-sub-tile-per-wave body QT times over the workgroup's rows: its registers stay below the fp16 body's, so the
+            // guard costs the fast path no occupancy (D = 64, QT = 2: 128 registers = 4 waves per SIMD; the QT = 2 hi + lo body needs 136).  The
+            // abandoned K image's DMA is drained first (the exact body stages it again).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            int qt2 = qt, head2 = head, b2 = b;      // (laundered: the exact body shares no value with the abandoned one, so the fast path's registers
+            asm volatile("" : "+s"(qt2), "+s"(head2), "+s"(b2));     //  are not held across the branch for its sake)
+            for (int sub = 0; sub < QT; ++sub) prefill_varlen_body<D, false, 1, false>(a, lds, qt2 * QT + sub, head2, b2);
+        }
+    } else {
+        prefill_varlen_body<D, PAGED, QT, PV == 1>(a, lds, qt, head, b);
     }
 }
 
@@ -692,8 +754,12 @@ template <int D, int QT>
 int launch_q(const PrefillArgs& a, hipStream_t stream) {
     dim3 grid(a.h, a.batch, (a.max_seqlen_q + 64 * QT - 1) / (64 * QT));
     if (a.kernel == 3) {                                         // NVH_PREFILL_TILED_F16V: v holds fp16 rows (measurement variant; never paged)
-        hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT, true>), grid, dim3(256), 0, stream, a);
+        hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT, 1>), grid, dim3(256), 0, stream, a);
         return check_launch("prefill_varlen_f16v");
+    }
+    if (a.v16) {                                                 // nvh_prefill_varlen_pv16: fp16 P V unless the conversion raised the guard
+        hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT, 2>), grid, dim3(256), 0, stream, a);
+        return check_launch("prefill_varlen_pv16");
     }
     if (a.block_tables) hipLaunchKernelGGL((prefill_varlen_kernel<D, true, QT>), grid, dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((prefill_varlen_kernel<D, false, QT>), grid, dim3(256), 0, stream, a);

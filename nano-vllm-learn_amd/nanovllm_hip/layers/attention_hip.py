@@ -17,7 +17,7 @@ from ..utils.context import get_context
 class Attention(nn.Module):
 
     def __init__(self, num_heads, head_dim, scale, num_kv_heads, block_size: int = 256, fused_decode: bool = True,
-                 prefill_pv_fp16: bool = False):
+                 prefill_pv_fp16=None):
         super().__init__()
         self.num_heads = num_heads
         self.head_dim = head_dim
@@ -25,7 +25,8 @@ class Attention(nn.Module):
         self.num_kv_heads = num_kv_heads
         self.block_size = block_size
         self.fused_decode = fused_decode        # one C-ABI call for store + attend on the decode step
-        # OPT-IN: prefill P V on fp16 operands for sequences of >= 1024 keys (1.2-1.4x; error <= 2^-12 * max|v| instead of 6e-6; ops.flash_attn_varlen_func)
+        # prefill P V on the fp16 matrix pipe (ops.flash_attn_varlen_func pv_fp16): None = the library's rule (bf16 output, packed rows, >= 1024 keys per sequence;
+        # range-guarded, falls back by itself), False = never (P as bf16 hi + lo, 6e-6 instead of <= 2^-12 * max|v|), True = at every length
         self.prefill_pv_fp16 = prefill_pv_fp16
         self.k_cache = self.v_cache = torch.tensor([])
 
@@ -84,7 +85,7 @@ class Attention(nn.Module):
                                            max_seqlen_q=context.max_seqlen_q, cu_seqlens_q=context.cu_seqlens_q,
                                            max_seqlen_k=context.max_seqlen_k, cu_seqlens_k=context.cu_seqlens_k,
                                            softmax_scale=self.scale, causal=True, block_table=context.block_tables,
-                                           pv_fp16=self.prefill_pv_fp16 and context.max_seqlen_k >= 1024)
+                                           pv_fp16=self.prefill_pv_fp16 if context.block_tables is None else False)
         else:
             if not have_cache:
                 raise RuntimeError("decode needs an allocated KV cache (k_cache/v_cache not bound)")

@@ -181,23 +181,26 @@ def decode_step(q, k_new, v_new, k_cache, v_cache, slot_mapping, cache_seqlens, 
 
 
 # --------------------------------------------------------------------------------------- prefill
+PV16_MIN_KEYS = 1024      # fp16 P V (nvh_prefill_varlen_pv16) by default from this many keys per sequence on: below, the conversion launch costs what it saves
+
+
 def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu_seqlens_k, softmax_scale=None,
-                           causal=True, block_table=None, out_dtype=None, kernel=None, short_waves=0, pv_fp16=False):
+                           causal=True, block_table=None, out_dtype=None, kernel=None, short_waves=0, pv_fp16=None):
     """Packed varlen causal attention, drop-in for the call at attention.py:93-96.
 
     q [Tq, H, D]; without block_table k/v are [Tk, KVH, D] (any row stride); with block_table they are
     the paged caches [NB, bs, KVH, D] and sequence i reads its keys through block_table[i].
-    kernel ("auto" | "tiled" | "short"), short_waves: tests / A-B only (nvh_prefill_varlen_variant).
-    pv_fp16 (OPT-IN, off by default; ignored with a block_table): convert v to fp16 (one elementwise launch) and run P V on fp16 operands
-    (NVH_PREFILL_TILED_F16V): 1.2-1.4x faster at S >= 1024, P rounded to 11 bits — error <= 2^-12 * max|v| (4.5e-4 on the reference goldens,
-    against 6e-6 for the default bf16 hi + lo form) and |v| <= 65504 required; DESIGN.md section 12.2."""
-    if pv_fp16 and block_table is None and kernel is None:
-        _require_gpu_bf16(v=v)
-        assert v.dim() == 3 and v.stride(-1) == 1 and v.stride(1) == v.shape[2]
-        v16 = torch.empty(v.shape, dtype=torch.float16, device=v.device)
-        _lib.check(_lib.load().nvh_bf16_rows_to_f16(v16.data_ptr(), v.data_ptr(), v.shape[0], v.shape[1] * v.shape[2], v.stride(0), v16.stride(0), _stream()),
-                   "nvh_bf16_rows_to_f16")
-        v, kernel = v16, "tiled_f16v"
+    kernel ("auto" | "tiled" | "short" | "tiled_f16v"), short_waves: tests / A-B only (nvh_prefill_varlen_variant).
+    pv_fp16: P V on the fp16 matrix pipe (nvh_prefill_varlen_pv16: V converted to fp16 rows in a scratch buffer with a range guard, P rounded to
+    11 bits; a V value that does not fit fp16 makes the kernel itself fall back to the exact form, no host read).  None (default) = where it pays and
+    is invisible: bf16 output (whose own rounding, 2^-9 |o|, is 8x coarser than P's), no block_table, max_seqlen_k >= PV16_MIN_KEYS; True = always
+    (no block_table); False = never (P as bf16 hi + lo, 6e-6).  Error of the fp16 form <= 2^-12 * max|v|: 4.5e-4 on the reference goldens (the
+    reference's flash backend rounds P to a single bf16, 8 bits).  DESIGN.md section 12.2."""
+    if kernel is not None or short_waves or block_table is not None:
+        assert not pv_fp16 or kernel == "tiled_f16v", "pv_fp16 goes with the default kernel choice and packed k / v rows"
+        pv_fp16 = False
+    elif pv_fp16 is None:
+        pv_fp16 = (out_dtype in (None, torch.bfloat16)) and int(max_seqlen_k) >= PV16_MIN_KEYS
     if not causal:
         raise NotImplementedError("the reference only ever calls this with causal=True (attention.py:96)")
     tq, h, hd = q.shape
@@ -229,6 +232,14 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
     tail = (out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), bt_ptr, batch,
             int(max_seqlen_q), int(max_seqlen_k), h, kvh, hd, bs, max_blocks, q.stride(0), k_stride, v_stride, bt_stride,
             float(softmax_scale), NVH_BF16, _out_code(out.dtype), _stream())
+    if pv_fp16:
+        lib = _lib.load()
+        scratch = torch.empty(lib.nvh_prefill_pv16_scratch_bytes(tk, kvh, hd), dtype=torch.uint8, device=q.device)
+        rc = lib.nvh_prefill_varlen_pv16(out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), batch,
+                                         int(max_seqlen_q), int(max_seqlen_k), tk, h, kvh, hd, q.stride(0), k_stride, v_stride, float(softmax_scale),
+                                         NVH_BF16, _out_code(out.dtype), scratch.data_ptr(), scratch.numel(), _stream())
+        _lib.check(rc, "nvh_prefill_varlen_pv16")
+        return out
     if kernel is not None or short_waves:
         rc = _lib.load().nvh_prefill_varlen_variant(_lib.PREFILL_KERNELS[kernel or "auto"], int(short_waves), *tail)
     else:

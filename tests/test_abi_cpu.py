@@ -86,6 +86,14 @@ def test_argument_validation_without_gpu(lib):
     assert lib.nvh_qkv_rope_attend_status(None, None) == -5
     assert lib.nvh_bf16_rows_to_f16(p, p, 4, 100, 128, 128, None) == -2 and lib.nvh_bf16_rows_to_f16(p, p, 4, 128, 100, 128, None) == -3
     assert lib.nvh_bf16_rows_to_f16(None, None, 0, 128, 128, 128, None) == 0
+    # prefill with P V on the fp16 pipe: scratch size is a pure function of the shapes; argument errors before any stream operation
+    assert lib.nvh_prefill_pv16_scratch_bytes(100, 2, 64) == 256 + 100 * 2 * 64 * 2 and lib.nvh_prefill_pv16_scratch_bytes(0, 2, 64) == 0
+    pv = (p, p, p, p, p, p, 2, 1024, 1024, 2048, 14, 2, 64, 896, 128, 128, 0.125, 0, 0)
+    assert lib.nvh_prefill_varlen_pv16(*pv, None, 0, None) == -5                      # no scratch
+    assert lib.nvh_prefill_varlen_pv16(*pv, p, 4096, None) == -4                      # scratch too small
+    assert b"scratch" in lib.nvh_last_error()
+    assert lib.nvh_prefill_varlen_pv16(*pv[:9], 0, *pv[10:], p, 1 << 20, None) == -4  # total_k missing
+    assert lib.nvh_prefill_varlen_pv16(p, p, p, p, p, p, 0, 0, 0, 0, 14, 2, 64, 896, 128, 128, 0.125, 0, 0, None, 0, None) == 0   # empty batch
 
 
 def test_ops_refuse_cpu_tensors():

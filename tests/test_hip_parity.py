@@ -804,10 +804,56 @@ def test_config1_shape_bs1_in512_out512(ops):
     assert np.array_equal(kc.float().cpu().numpy(), kc_ref) and np.array_equal(vc.float().cpu().numpy(), vc_ref)
 
 
+@pytest.mark.parametrize("name", PREFILL)
+def test_prefill_pv16_golden_and_range_guard(ops, golden, name):
+    """nvh_prefill_varlen_pv16 (fp16 P x fp16 V behind a range guard): (1) forced on the reference goldens, fp32 output: inside the 1e-3 bar and visibly
+    not the hi + lo form; (2) ONE value of V that does not fit fp16 (1e5) makes the kernel itself take the exact form for THAT sequence: its rows equal the default
+    kernel's bit for bit, at a length with one and with two query sub-tiles per wave, while the batch's other sequence keeps the fp16 form; (3) inf in V is not a range problem (converts to inf)."""
+    g = golden(name)
+    q, k, v = dev_bf16(g["q"]), dev_bf16(g["k"]), dev_bf16(g["v"])
+    cu = dev_i32(g["cu_seqlens"])
+    mx = int(np.diff(g["cu_seqlens"]).max())
+    o32 = ops.flash_attn_varlen_func(q, k, v, mx, cu, mx, cu, out_dtype=torch.float32, pv_fp16=True)
+    torch.cuda.synchronize()
+    err = np.abs(o32.cpu().numpy() - g["expected"]).max()
+    short = mx <= 128 and (len(g["cu_seqlens"]) - 1) * k.shape[1] >= 128               # (a batch the short-sequence kernel takes keeps hi + lo)
+    assert (err <= 2e-5) if short else (2e-5 < err <= ATOL), f"{name}: pv16 max abs err {err:.3e}"
+    H, KVH, D = q.shape[1], k.shape[1], q.shape[2]
+    for S in (1100, 2304):
+        gen = torch.Generator().manual_seed(S)
+        qkv = torch.randn(S + 40, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+        ql, kl, vl = qkv[:, :H * D].view(-1, H, D), qkv[:, H * D:(H + KVH) * D].view(-1, KVH, D), qkv[:, (H + KVH) * D:].view(-1, KVH, D)
+        cul = dev_i32(np.array([0, S, S + 40], np.int32))
+        exact = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=False)
+        fast = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=True)
+        assert 2e-5 < (fast - exact).abs().max().item() <= ATOL
+        auto16 = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul)                # default rule: bf16 output, >= 1024 keys -> the fp16 form
+        assert torch.equal(auto16, ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, pv_fp16=True))
+        vl[S // 2, KVH - 1, 3] = 1e5                                                   # does not fit fp16: the flag must send every workgroup of sequence 0 to hi + lo
+        exact = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=False)
+        guarded = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=True)
+        torch.cuda.synchronize()
+        assert torch.isfinite(guarded).all() and torch.equal(guarded[:S], exact[:S]), f"S={S}: guard fall-back differs from the exact kernel"
+        d1 = (guarded[S:] - exact[S:]).abs().max().item()                              # the flags are per 64 rows, the decision per sequence: the second
+        assert 0 < d1 <= ATOL                                                          # sequence (rows in range) keeps the fp16 form
+        vl[S // 2, KVH - 1, 3] = float("inf")                                          # inf stays inf in fp16: no fall-back needed, same non-finite pattern
+        a = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=True)
+        b = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=False)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.isfinite(a), torch.isfinite(b))
+        fin = torch.isfinite(b)
+        assert (a[fin] - b[fin]).abs().max().item() <= ATOL
+    # the default rule leaves short batches and fp32 output alone
+    S = 300
+    cul = dev_i32(np.array([0, S], np.int32))
+    qs, ks, vs = ql[:S], kl[:S], vl[:S].clone().nan_to_num_(posinf=1.0)
+    assert torch.equal(ops.flash_attn_varlen_func(qs, ks, vs, S, cul, S, cul), ops.flash_attn_varlen_func(qs, ks, vs, S, cul, S, cul, pv_fp16=False))
+
+
 @pytest.mark.gpu
-def test_attention_module_opt_in_fp16_pv_prefill():
-    """Attention(prefill_pv_fp16=True): prefill of sequences with >= 1024 keys converts v to fp16 and runs P V on fp16 operands; shorter
-    batches and prefix-cached prefill keep the default form.  Against the oracle at the 1e-3 bar (N(0,1) inputs), and against the default module."""
+def test_attention_module_fp16_pv_prefill_rule():
+    """Attention(prefill_pv_fp16=None, the default): prefill of sequences with >= 1024 keys runs P V on the fp16 pipe (range-guarded); shorter batches
+    keep the hi + lo form; prefill_pv_fp16=False never does.  Against the oracle at the 1e-3 bar (N(0,1) inputs), and against each other."""
     from nanovllm_hip import reset_context, set_context
     from nanovllm_hip.layers.attention_hip import Attention
     H, KVH, D = 14, 2, 64
@@ -819,12 +865,12 @@ def test_attention_module_opt_in_fp16_pv_prefill():
         q, k, v = qkv.split([H * D, KVH * D, KVH * D], dim=-1)
         cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
         exp = O.prefill_varlen(q.float().cpu().view(T, H, D).numpy(), k.float().cpu().view(T, KVH, D).numpy(), v.float().cpu().view(T, KVH, D).numpy(), cu, cu)
-        for opt in (False, True):
+        for opt in (False, None):
             attn = Attention(H, D, D ** -0.5, KVH, prefill_pv_fp16=opt)
             set_context(True, dev_i32(cu), dev_i32(cu), max(lens), max(lens), None, None, None)
             o = attn(q, k, v).float().cpu().view(T, H, D).numpy()
             reset_context()
             assert (np.abs(o - exp) <= ATOL + BF16_ULP * np.abs(exp)).all()
             outs[tuple(lens), opt] = o
-    assert not np.array_equal(outs[(1100, 37), True], outs[(1100, 37), False])       # the long batch took the fp16 form
-    assert np.array_equal(outs[(200, 90), True], outs[(200, 90), False])             # the short one did not
+    assert not np.array_equal(outs[(1100, 37), None], outs[(1100, 37), False])       # the long batch took the fp16 form
+    assert np.array_equal(outs[(200, 90), None], outs[(200, 90), False])             # the short one did not

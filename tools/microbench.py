@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time a HIP graph of `layers` back-to-back launches")
     ap.add_argument("--fused", action="store_true", help="decode: time nvh_decode_step (store + attend)")
     ap.add_argument("--seq", type=int, default=1024, help="prefill: sequence length")
+    ap.add_argument("--pv", default="auto", choices=["auto", "fp16", "exact"], help="prefill: P V form (ops.flash_attn_varlen_func pv_fp16 = None / True / False)")
     ap.add_argument("--variant", default=None, help="decode: chunked | chunked_p64 | chunked_p128 | chunked_p256 | split_mfma | split_valu (nvh_paged_decode_variant); prefill: auto | tiled | short | tiled_f16v")
     ap.add_argument("--waves", type=int, default=0, help="decode (chunked, D=64): 4 or 8 waves; prefill short kernel: 8 or 16")
     ap.add_argument("--chunks", type=int, default=0, help="decode (chunked): workgroups per (sequence, kv head)")
@@ -125,9 +126,11 @@ def main():
         cu = torch.arange(0, t + 1, s, dtype=torch.int32, device=dev)
         if args.variant == "tiled_f16v":
             v = v.to(torch.float16)                              # (converted once, outside the timed loop: what a producer-side conversion would hand over)
-        us = time_loop(lambda l: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu, kernel=args.variant, short_waves=args.waves), 1, args.iters, args.warmup)
+        pv = None if args.variant or args.waves else {"auto": None, "fp16": True, "exact": False}[args.pv]
+        us = time_loop(lambda l: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu, kernel=args.variant, short_waves=args.waves, pv_fp16=pv), 1, args.iters, args.warmup)
         flops = b * 4 * d * h * s * (s + 1) / 2
-        print(json.dumps({"mode": "prefill", "batch": b, "seq": s, "shape": [h, kvh, d], "us_per_call": round(us, 1),
+        form = args.variant or ("fp16 P V (guarded, conversion inside the call)" if pv is True or (pv is None and not args.waves and s >= ops.PV16_MIN_KEYS) else "bf16 hi + lo")
+        print(json.dumps({"mode": "prefill", "batch": b, "seq": s, "shape": [h, kvh, d], "form": form, "us_per_call": round(us, 1),
                           "TFLOPs": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}))
 
 
