@@ -200,13 +200,16 @@ int nvh_bf16_rows_to_f16(void* out, const void* in, int n_rows, int row_elems, i
  * sequence's rows and runs fp16 P x fp16 V for it, or — a flag set, or the sequence reaching past total_k — the exact bf16 hi + lo form on the caller's own
  * V rows, i.e. exactly nvh_prefill_varlen for that sequence.  Numerics of the fp16 form: P in [0, 1] rounded to 11 significant bits, products accumulated
  * in fp32: |error| <= 2^-12 * max|v| per output element, 4.5e-4 on the reference's golden vectors (N(0,1) values; hi + lo: 6e-6; bf16 OUTPUT rounding
- * alone: 2^-9 * |o|).  Shapes the short-sequence kernel takes (max_seqlen_k <= 128, >= 128 (sequence, kv head) pairs) run that kernel unchanged
- * (hi + lo; scratch untouched).
+ * alone: 2^-9 * |o|).  Shapes the short-sequence kernel takes (max_seqlen_q <= max_seqlen_k <= 128, >= 128 (sequence, kv head) pairs:
+ * nvh_prefill_pv16_uses_scratch() == 0, scratch may be NULL) run ONE launch: at head_dim 64 and more than 64 keys each workgroup converts its resident
+ * V images to fp16 in LDS, range check folded into the barrier that publishes them (a (sequence, kv head) pair out of range keeps hi + lo); otherwise
+ * that kernel runs unchanged.
  *   total_k        rows of k / v (= cu_seqlens_k[batch] on the host)
  *   scratch        device memory of at least nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd) bytes (flags: 4 * ceil(total_k / 64) rounded up to 256, then
  *                  total_k*kvh*hd*2), 16-byte aligned, owned by the caller, not shared with a call in flight on another stream
  */
 size_t nvh_prefill_pv16_scratch_bytes(int total_k, int kvh, int hd);
+int nvh_prefill_pv16_uses_scratch(int batch, int max_seqlen_q, int max_seqlen_k, int kvh, int hd);
 int nvh_prefill_varlen_pv16(void* out, const void* q, const void* k, const void* v,
                             const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, int batch, int max_seqlen_q, int max_seqlen_k, int total_k,
                             int h, int kvh, int hd, int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,

@@ -236,7 +236,7 @@ static int prefill_varlen_impl(int kernel, int short_waves, void* out, const voi
                        int h, int kvh, int hd, int block_size, int max_blocks,
                        int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                        int64_t bt_row_stride, float scale, int dtype, int out_dtype, void* stream,
-                       int total_k = 0, void* pv16_scratch = nullptr, size_t pv16_scratch_bytes = 0) {
+                       bool pv16 = false, int total_k = 0, void* pv16_scratch = nullptr, size_t pv16_scratch_bytes = 0) {
     if (batch == 0 || max_seqlen_q == 0) return 0;
     if (kernel < 0 || kernel > 3 || (kernel == 3 && block_tables) || (short_waves != 0 && short_waves != 8 && short_waves != 16)) {
         set_error("prefill_varlen: kernel %d / short_waves %d not supported", kernel, short_waves);
@@ -279,16 +279,21 @@ static int prefill_varlen_impl(int kernel, int short_waves, void* out, const voi
     a.out_f32 = out_dtype == NVH_F32;
     a.stamps = g_stamps;
     a.kernel = kernel; a.short_waves = short_waves;
-    if (pv16_scratch) {
-        // fp16 P V on an fp16 copy of V made here: [one range flag per 64 rows, padded to 256 bytes][total_k rows of kvh*hd fp16].  Two launches, no host
-        // read, nothing to clear: convert (every workgroup writes its group's flag), attend (a sequence with a flagged group falls back to `v` itself).
+    if (pv16) {
         if (block_tables) { set_error("prefill_varlen_pv16: not with a block table (V is read from the cache)"); return NVH_E_SHAPE; }
-        if (total_k <= 0 || !aligned16(pv16_scratch) || pv16_scratch_bytes < nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd)) {
-            set_error("prefill_varlen_pv16: scratch of %zu bytes, %zu needed for %d rows (16-byte aligned)", pv16_scratch_bytes,
-                      nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd), total_k);
-            return NVH_E_WORKSPACE;
-        }
-        if (a.max_seqlen_k > 128 || a.max_seqlen_q > a.max_seqlen_k || a.batch * a.kvh < 128) {     // not the short-sequence kernel's shapes (it keeps hi + lo)
+        if (!nvh_prefill_pv16_uses_scratch(batch, max_seqlen_q, max_seqlen_k, kvh, hd)) {
+            // the short-sequence kernel's shapes: it converts its resident V images itself (head_dim 64, more than one key tile: below, the conversion
+            // costs what it saves; otherwise the kernel keeps hi + lo); scratch untouched
+            a.short_pv16 = hd == 64 && max_seqlen_k > 64;
+        } else {
+            // fp16 P V on an fp16 copy of V made here: [one range flag per 64 rows, padded to 256 bytes][total_k rows of kvh*hd fp16].  Two launches, no
+            // host read, nothing to clear: convert (every workgroup writes its group's flag), attend (a sequence with a flagged group falls back to `v`).
+            if (!pv16_scratch) { set_error("prefill_varlen_pv16: null scratch"); return NVH_E_NULL; }
+            if (total_k <= 0 || !aligned16(pv16_scratch) || pv16_scratch_bytes < nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd)) {
+                set_error("prefill_varlen_pv16: scratch of %zu bytes, %zu needed for %d rows (16-byte aligned)", pv16_scratch_bytes,
+                          nvh_prefill_pv16_scratch_bytes(total_k, kvh, hd), total_k);
+                return NVH_E_WORKSPACE;
+            }
             int32_t* flags = (int32_t*)pv16_scratch;
             uint16_t* v16 = (uint16_t*)((char*)pv16_scratch + pv16_header_bytes(total_k));
             rc = launch_bf16_rows_to_f16(v16, v, total_k, kvh * hd, v_row_stride, (int64_t)kvh * hd, flags, (hipStream_t)stream);
@@ -298,6 +303,12 @@ static int prefill_varlen_impl(int kernel, int short_waves, void* out, const voi
         }
     }
     return launch_prefill_varlen(a, (hipStream_t)stream);
+}
+
+int nvh_prefill_pv16_uses_scratch(int batch, int max_seqlen_q, int max_seqlen_k, int kvh, int hd) {
+    (void)hd;
+    const bool short_kernel = max_seqlen_k <= 128 && max_seqlen_q <= max_seqlen_k && (int64_t)batch * kvh >= 128;     // launch_short's rule (prefill_mfma.hip)
+    return short_kernel ? 0 : 1;
 }
 
 size_t nvh_prefill_pv16_scratch_bytes(int total_k, int kvh, int hd) {
@@ -310,9 +321,8 @@ int nvh_prefill_varlen_pv16(void* out, const void* q, const void* k, const void*
                             int h, int kvh, int hd, int64_t q_row_stride, int64_t k_row_stride, int64_t v_row_stride,
                             float scale, int dtype, int out_dtype, void* scratch, size_t scratch_bytes, void* stream) {
     if (batch == 0 || max_seqlen_q == 0) return 0;
-    if (!scratch) { set_error("prefill_varlen_pv16: null scratch"); return NVH_E_NULL; }
     return prefill_varlen_impl(0, 0, out, q, k, v, cu_seqlens_q, cu_seqlens_k, nullptr, batch, max_seqlen_q, max_seqlen_k, h, kvh, hd,
-                               0, 0, q_row_stride, k_row_stride, v_row_stride, 0, scale, dtype, out_dtype, stream, total_k, scratch, scratch_bytes);
+                               0, 0, q_row_stride, k_row_stride, v_row_stride, 0, scale, dtype, out_dtype, stream, true, total_k, scratch, scratch_bytes);
 }
 
 int nvh_prefill_varlen(void* out, const void* q, const void* k, const void* v,

@@ -181,6 +181,7 @@ struct PrefillArgs {
     unsigned long long* stamps;  // diagnostic builds only (NVH_STAMPS); null otherwise
     int kernel;                  // 0 auto, 1 tiled kernel only, 2 short-sequence kernel (error if the shape does not allow it)
     int short_waves;             // short-sequence kernel: 0 auto, 8 or 16 waves per workgroup
+    int short_pv16 = 0;                   // nvh_prefill_varlen_pv16 on the short-sequence kernel's shapes: convert V to fp16 inside the kernel (D = 64)
     const uint16_t* v16 = nullptr;        // nvh_prefill_varlen_pv16: fp16 copy of the V rows [Tk, KVH, D] (row stride v16_row_stride) ...
     int64_t v16_row_stride = 0;
     int pv16_rows = 0;                    // rows converted (total_k of the call): a sequence reaching past them takes the exact form

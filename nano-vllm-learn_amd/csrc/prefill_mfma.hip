@@ -50,8 +50,19 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         if (a.stamps && tid == 0 && (k) < 32)                                                            \
             a.stamps[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * gridDim.z + (gridDim.z - 1 - blockIdx.z)) * 32 + (k)] = t_; \
     } while (0)
+// short-sequence kernel: 16 slots per WAVE (lane 0), [(b * kvh + kh) * NW + wave]
+#define SK_STAMP(k)                                                                                      \
+    do {                                                                                                 \
+        unsigned long long t_;                                                                           \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                  \
+        __builtin_amdgcn_sched_barrier(0);                                                               \
+        if (a.stamps && lane == 0 && (k) < 16)                                                           \
+            a.stamps[(((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * NW + wave) * 16 + (k)] = t_;      \
+    } while (0)
 #else
 #define PF_STAMP(k) do {} while (0)
+#define SK_STAMP(k) do {} while (0)
 #endif
 
 // QT = 16-row query sub-tiles per wave (template parameter): with QT = 2 every K / V fragment read from LDS feeds both
@@ -527,7 +538,12 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
     constexpr int ROWB = D * 2, LPT = D / 8, TPI = 64 / LPT, IMG = BN * ROWB, NI = IMG / 1024;
     constexpr int STEPS = D / 32, DT = D / 16, NT = BN / 16;
     static_assert((NKT - 1) * 2 * IMG + IMG + 48 * ROWB < 65536, "transposed V reads address tiles through the 16-bit ds offset");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NKT * 2 * IMG];   // [tile][K | V]
+    // PV16 (nvh_prefill_varlen_pv16 on this kernel's shapes, D = 64): a third image per tile holds V as fp16, converted HERE once per workgroup (one
+    // 16-byte chunk per lane) with the range check folded into the barrier that publishes it; P V then runs as one fp16 MFMA per operand pair.
+    constexpr bool PV16 = D == 64;
+    constexpr int V16_BASE = NKT * 2 * IMG;
+    static_assert(!PV16 || V16_BASE + (NKT - 1) * IMG + 48 * ROWB < 65536, "fp16 V images within the 16-bit ds offset");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NKT * 2 * IMG + (PV16 ? NKT * IMG : 0)];   // [tile][K | V], then [tile][V as fp16]
 
     const int kh = blockIdx.x, b = blockIdx.y;
     const int q_beg = a.cu_q[b], q_end = a.cu_q[b + 1];
@@ -543,6 +559,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
     int n_tiles = (sk + BN - 1) / BN;                // <= NKT by the caller's contract (max_seqlen_k bounds every sequence);
     if (n_tiles > NKT) n_tiles = NKT;                // a caller that understated it must not make the staging loop write past the array
 
+    SK_STAMP(0);
     // ---- stage every K / V tile of the sequence: DMA instruction `ins` = 1 KiB of one image, dealt round-robin to the waves
     {
         const int dp = lane % LPT, dr = lane / LPT;
@@ -582,8 +599,33 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
     bf16x8 qf[STEPS];
     int t = wave;
     if (t < n_tasks) load_q(t, qf);
+    SK_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // this wave's share of the images (and its first Q)
+    SK_STAMP(2);
     __syncthreads();                                                             // everyone's: K / V are resident from here on
+    SK_STAMP(3);
+    [[maybe_unused]] int sk_round = 0;
+    bool use16 = false;                              // workgroup-uniform
+    if constexpr (PV16) {
+        if (a.short_pv16) {
+            uint32_t big = 0;                        // largest finite |v| of this lane's chunks, as fp32 bits
+            for (int c = tid; c < n_tiles * (IMG / 16); c += NW * 64) {
+                const int tile = c / (IMG / 16), off = (c - tile * (IMG / 16)) * 16;
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(lds + tile * 2 * IMG + IMG + off);
+                u32x4 h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t lo = raw[j] << 16, hi = raw[j] & 0xffff0000u;
+                    h[j] = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(__builtin_bit_cast(float, lo), __builtin_bit_cast(float, hi)));   // exact in range
+                    const uint32_t alo = lo & 0x7fffffffu, ahi = hi & 0x7fffffffu;
+                    if (alo < 0x7f800000u) big = big > alo ? big : alo;          // inf / NaN stay inf / NaN
+                    if (ahi < 0x7f800000u) big = big > ahi ? big : ahi;
+                }
+                *reinterpret_cast<u32x4*>(lds + V16_BASE + tile * IMG + off) = h;
+            }
+            use16 = !__syncthreads_or(big > 0x477f0000u);                        // (65504 as fp32 is 0x477fe000; largest bf16 below: 0x477f0000)
+        }
+    }
 
     // transposed V reads: the per-lane part of the address is invariant; tile, image, 32-key half and the +16-row partner are
     // immediates (see the tiled kernel)
@@ -596,6 +638,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
         for (int tt = 0; tt < DT; ++tt) vaddr[tt] = lds_offset(lds + R0 * ROWB + (vp & 1) * 8 + (((2 * tt + (vp >> 1)) ^ swz) * 16));
     }
 
+    auto run_tasks = [&](auto f16c) {
+    constexpr bool F16 = decltype(f16c)::value;
     for (; t < n_tasks; t += NW) {
         bf16x8 qn[STEPS];
         if (t + NW < n_tasks) load_q(t + NW, qn);                                // in flight while this task computes
@@ -636,25 +680,26 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
                         sT[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[st], sT[tt], 0, 0, 0);
                     }
                 } else {
-                    sT[tt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};                          // (dead group: never looked at below; defined for the asm operand list)
                 }
             }
             asm volatile("s_nop 7" : "+v"(sT[0]), "+v"(sT[1]), "+v"(sT[2]), "+v"(sT[3]));   // wait states: MFMA results -> the asm max chain
-            if (kv0 + BN - 1 > q0 + shift || kv0 + BN > sk) {                    // wave-uniform: the tile reaches the diagonal or the end
-                const int limit = (q_pos < sk - 1 ? q_pos : sk - 1) - kv0 - 4 * lg;     // see the tiled kernel: constant <= per-lane limit
+            // The softmax work too is done per LIVE 16-key group (wave-uniform guards): at S = 128 a quarter of the groups a tile body
+            // touches are dead, and on a sub-tile's diagonal tile mask + max + exp2 of a dead group cost as much as those of a live one.
+            const bool masked = kv0 + BN - 1 > q0 + shift || kv0 + BN > sk;      // wave-uniform: the tile reaches the diagonal or the end
+            const int limit = (q_pos < sk - 1 ? q_pos : sk - 1) - kv0 - 4 * lg;  // see the tiled kernel: constant <= per-lane limit
+            float mx = -INFINITY;
 #pragma unroll
-                for (int tt = 0; tt < NT; ++tt)
+            for (int tt = 0; tt < NT; ++tt) {
+                if (tt < n_tt) {
+                    if (masked) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sT[tt][r] = (16 * tt + r <= limit) ? sT[tt][r] : -INFINITY;
+                        for (int r = 0; r < 4; ++r) sT[tt][r] = (16 * tt + r <= limit) ? sT[tt][r] : -INFINITY;
+                    }
+                    mx = max3(mx, sT[tt][0], sT[tt][1]);
+                    mx = max3(mx, sT[tt][2], sT[tt][3]);
+                }
             }
-            float mx = max3(sT[0][0], sT[0][1], sT[0][2]);
-            mx = max3(mx, sT[0][3], sT[1][0]);
-            mx = max3(mx, sT[1][1], sT[1][2]);
-            mx = max3(mx, sT[1][3], sT[2][0]);
-            mx = max3(mx, sT[2][1], sT[2][2]);
-            mx = max3(mx, sT[2][3], sT[3][0]);
-            mx = max3(mx, sT[3][1], sT[3][2]);
-            mx = max2(mx, sT[3][3]);
             mx = max_xor16(mx);
             mx = max_xor32(mx);
             mx *= a.scale_log2;
@@ -663,16 +708,21 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
             const f32x2 sc2 = {a.scale_log2, a.scale_log2}, mm2 = {-m_use, -m_use};
             f32x2 psum2 = {0.f, 0.f};
 #pragma unroll
-            for (int tt = 0; tt < NT; ++tt)
+            for (int tt = 0; tt < NT; ++tt) {
+                if (tt < n_tt) {
 #pragma unroll
-                for (int r = 0; r < 4; r += 2) {
-                    const f32x2 sv = {sT[tt][r], sT[tt][r + 1]};
-                    const f32x2 z = __builtin_elementwise_fma(sv, sc2, mm2);
-                    const f32x2 e = {fast_exp2(z[0]), fast_exp2(z[1])};
-                    sT[tt][r] = e[0];
-                    sT[tt][r + 1] = e[1];
-                    psum2 += e;
+                    for (int r = 0; r < 4; r += 2) {
+                        const f32x2 sv = {sT[tt][r], sT[tt][r + 1]};
+                        const f32x2 z = __builtin_elementwise_fma(sv, sc2, mm2);
+                        const f32x2 e = {fast_exp2(z[0]), fast_exp2(z[1])};
+                        sT[tt][r] = e[0];
+                        sT[tt][r + 1] = e[1];
+                        psum2 += e;
+                    }
+                } else {
+                    sT[tt] = f32x4{0.f, 0.f, 0.f, 0.f};                          // p = 0 (read only when its 32-key half has a live group)
                 }
+            }
             if constexpr (it > 0) {                                              // (a task's first tile starts from o = l = 0: nothing to rescale)
                 if (__builtin_amdgcn_ballot_w64(m_new != m_run) != 0) {          // some row's max moved: rescale (wave-uniform branch)
                     const float alpha = fast_exp2(m_run - m_use);                // m_run = -inf -> 0
@@ -690,36 +740,50 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const f32x2 pv = {sT[2 * hh + (j >> 1)][2 * (j & 1)], sT[2 * hh + (j >> 1)][2 * (j & 1) + 1]};
-                    const uint32_t hp = cvt_pk_bf16(pv[0], pv[1]);
-                    const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
-                    const f32x2 lo = pv - hf;
-                    hraw[j] = hp;
-                    lraw[j] = cvt_pk_bf16(lo[0], lo[1]);
+                    if constexpr (F16) {
+                        hraw[j] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pv, f16x2v));       // v_cvt_pk_f16_f32, round to nearest even
+                    } else {
+                        const uint32_t hp = cvt_pk_bf16(pv[0], pv[1]);
+                        const f32x2 hf = {__builtin_bit_cast(float, hp << 16), __builtin_bit_cast(float, hp & 0xffff0000u)};
+                        const f32x2 lo = pv - hf;
+                        hraw[j] = hp;
+                        lraw[j] = cvt_pk_bf16(lo[0], lo[1]);
+                    }
                 }
-                const bf16x8 p_hi = *reinterpret_cast<const bf16x8*>(&hraw), p_lo = *reinterpret_cast<const bf16x8*>(&lraw);
+                constexpr int VIMG = F16 ? V16_BASE + it * IMG : VOFF;           // same layout, same swizzle: only the element type differs
                 u32x2 vlo[DT], vhi[DT];
 #pragma unroll
                 for (int tt = 0; tt < DT; ++tt) {
                     if (hh == 0) {
-                        vlo[tt] = ds_read_tr16_b64_asm<VOFF>(vaddr[tt]);
-                        vhi[tt] = ds_read_tr16_b64_asm<VOFF + 16 * ROWB>(vaddr[tt]);
+                        vlo[tt] = ds_read_tr16_b64_asm<VIMG>(vaddr[tt]);
+                        vhi[tt] = ds_read_tr16_b64_asm<VIMG + 16 * ROWB>(vaddr[tt]);
                     } else {
-                        vlo[tt] = ds_read_tr16_b64_asm<VOFF + 32 * ROWB>(vaddr[tt]);
-                        vhi[tt] = ds_read_tr16_b64_asm<VOFF + 48 * ROWB>(vaddr[tt]);
+                        vlo[tt] = ds_read_tr16_b64_asm<VIMG + 32 * ROWB>(vaddr[tt]);
+                        vhi[tt] = ds_read_tr16_b64_asm<VIMG + 48 * ROWB>(vaddr[tt]);
                     }
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                bf16x8 vf[DT];
+                if constexpr (F16) {
+                    const f16x8 p16 = __builtin_bit_cast(f16x8, hraw);
 #pragma unroll
-                for (int tt = 0; tt < DT; ++tt) {
-                    const u32x4 raw = {vlo[tt][0], vlo[tt][1], vhi[tt][0], vhi[tt][1]};
-                    vf[tt] = *reinterpret_cast<const bf16x8*>(&raw);
+                    for (int tt = 0; tt < DT; ++tt) {
+                        const u32x4 raw = {vlo[tt][0], vlo[tt][1], vhi[tt][0], vhi[tt][1]};
+                        o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, raw), p16, o[tt], 0, 0, 0);
+                    }
+                } else {
+                    const bf16x8 p_hi = *reinterpret_cast<const bf16x8*>(&hraw), p_lo = *reinterpret_cast<const bf16x8*>(&lraw);
+                    bf16x8 vf[DT];
+#pragma unroll
+                    for (int tt = 0; tt < DT; ++tt) {
+                        const u32x4 raw = {vlo[tt][0], vlo[tt][1], vhi[tt][0], vhi[tt][1]};
+                        vf[tt] = *reinterpret_cast<const bf16x8*>(&raw);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt], p_hi, o[tt], 0, 0, 0);
+#pragma unroll
+                    for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt], p_lo, o[tt], 0, 0, 0);
                 }
-#pragma unroll
-                for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt], p_hi, o[tt], 0, 0, 0);
-#pragma unroll
-                for (int tt = 0; tt < DT; ++tt) o[tt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[tt], p_lo, o[tt], 0, 0, 0);
             }
         };
         if (0 < n_t) tile(std::integral_constant<int, 0>{});
@@ -727,6 +791,7 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
         if constexpr (NKT > 2) { if (2 < n_t) tile(std::integral_constant<int, 2>{}); }
         if constexpr (NKT > 3) { if (3 < n_t) tile(std::integral_constant<int, 3>{}); }
 
+        SK_STAMP(4 + 2 * sk_round);
         // ---- finalise the task: total row sum over the 4 lane groups, normalise, store 4 contiguous dims per tile
         float l = sum_xor16(l_run);
         l = sum_xor32(l);
@@ -747,7 +812,17 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
         }
 #pragma unroll
         for (int st = 0; st < STEPS; ++st) qf[st] = qn[st];
+        SK_STAMP(4 + 2 * sk_round + 1);                                          // (diagnostic builds: 4 + 2r = tiles of round r done, 5 + 2r = stores issued)
+        ++sk_round;
     }
+    };
+    if constexpr (PV16) {
+        if (use16) run_tasks(std::true_type{});
+        else run_tasks(std::false_type{});
+    } else {
+        run_tasks(std::false_type{});
+    }
+    SK_STAMP(15);
 }
 
 template <int D, int QT>

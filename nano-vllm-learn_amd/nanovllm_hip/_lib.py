@@ -58,6 +58,7 @@ _SIGS = {
     "nvh_prefill_varlen_variant": (ctypes.c_int, [ctypes.c_int] * 2 + [ctypes.c_void_p] * 4 + [_c_i32p] * 3 + [ctypes.c_int] * 8 +
                                    [ctypes.c_int64] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "nvh_prefill_pv16_scratch_bytes": (ctypes.c_size_t, [ctypes.c_int] * 3),
+    "nvh_prefill_pv16_uses_scratch": (ctypes.c_int, [ctypes.c_int] * 5),
     "nvh_prefill_varlen_pv16": (ctypes.c_int, [ctypes.c_void_p] * 4 + [_c_i32p] * 2 + [ctypes.c_int] * 7 + [ctypes.c_int64] * 3 +
                                 [ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "nvh_bf16_rows_to_f16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]),

@@ -193,14 +193,18 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
     kernel ("auto" | "tiled" | "short" | "tiled_f16v"), short_waves: tests / A-B only (nvh_prefill_varlen_variant).
     pv_fp16: P V on the fp16 matrix pipe (nvh_prefill_varlen_pv16: V converted to fp16 rows in a scratch buffer with a range guard, P rounded to
     11 bits; a V value that does not fit fp16 makes the kernel itself fall back to the exact form, no host read).  None (default) = where it pays and
-    is invisible: bf16 output (whose own rounding, 2^-9 |o|, is 8x coarser than P's), no block_table, max_seqlen_k >= PV16_MIN_KEYS; True = always
+    is invisible: bf16 output (whose own rounding, 2^-9 |o|, is 8x coarser than P's), no block_table, max_seqlen_k >= PV16_MIN_KEYS or a batch the
+    short-sequence kernel takes (head_dim 64, <= 128 keys, >= 128 (sequence, kv head) pairs: it converts V inside the kernel); True = always
     (no block_table); False = never (P as bf16 hi + lo, 6e-6).  Error of the fp16 form <= 2^-12 * max|v|: 4.5e-4 on the reference goldens (the
     reference's flash backend rounds P to a single bf16, 8 bits).  DESIGN.md section 12.2."""
     if kernel is not None or short_waves or block_table is not None:
         assert not pv_fp16 or kernel == "tiled_f16v", "pv_fp16 goes with the default kernel choice and packed k / v rows"
         pv_fp16 = False
     elif pv_fp16 is None:
-        pv_fp16 = (out_dtype in (None, torch.bfloat16)) and int(max_seqlen_k) >= PV16_MIN_KEYS
+        # ... or on the short-sequence kernel's shapes (it converts its resident V images itself: no extra launch; the library's rule, prefill_mfma.hip launch_short)
+        short = (q.shape[2] == 64 and 64 < int(max_seqlen_k) <= 128 and int(max_seqlen_q) <= int(max_seqlen_k)
+                 and (cu_seqlens_q.numel() - 1) * k.shape[1] >= 128)
+        pv_fp16 = (out_dtype in (None, torch.bfloat16)) and (int(max_seqlen_k) >= PV16_MIN_KEYS or short)
     if not causal:
         raise NotImplementedError("the reference only ever calls this with causal=True (attention.py:96)")
     tq, h, hd = q.shape
@@ -234,10 +238,14 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
             float(softmax_scale), NVH_BF16, _out_code(out.dtype), _stream())
     if pv_fp16:
         lib = _lib.load()
-        scratch = torch.empty(lib.nvh_prefill_pv16_scratch_bytes(tk, kvh, hd), dtype=torch.uint8, device=q.device)
+        if int(max_seqlen_k) <= 128 and not lib.nvh_prefill_pv16_uses_scratch(batch, int(max_seqlen_q), int(max_seqlen_k), kvh, hd):
+            sc_ptr, sc_bytes = None, 0                           # the short-sequence kernel converts V in LDS: one launch, no scratch
+        else:
+            scratch = torch.empty(lib.nvh_prefill_pv16_scratch_bytes(tk, kvh, hd), dtype=torch.uint8, device=q.device)
+            sc_ptr, sc_bytes = scratch.data_ptr(), scratch.numel()
         rc = lib.nvh_prefill_varlen_pv16(out.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), batch,
                                          int(max_seqlen_q), int(max_seqlen_k), tk, h, kvh, hd, q.stride(0), k_stride, v_stride, float(softmax_scale),
-                                         NVH_BF16, _out_code(out.dtype), scratch.data_ptr(), scratch.numel(), _stream())
+                                         NVH_BF16, _out_code(out.dtype), sc_ptr, sc_bytes, _stream())
         _lib.check(rc, "nvh_prefill_varlen_pv16")
         return out
     if kernel is not None or short_waves:

@@ -90,6 +90,8 @@ def test_argument_validation_without_gpu(lib):
     assert lib.nvh_prefill_pv16_scratch_bytes(100, 2, 64) == 256 + 100 * 2 * 64 * 2 and lib.nvh_prefill_pv16_scratch_bytes(0, 2, 64) == 0
     pv = (p, p, p, p, p, p, 2, 1024, 1024, 2048, 14, 2, 64, 896, 128, 128, 0.125, 0, 0)
     assert lib.nvh_prefill_varlen_pv16(*pv, None, 0, None) == -5                      # no scratch
+    assert lib.nvh_prefill_pv16_uses_scratch(2, 1024, 1024, 2, 64) == 1 and lib.nvh_prefill_pv16_uses_scratch(128, 128, 128, 2, 64) == 0
+    assert lib.nvh_prefill_pv16_uses_scratch(16, 128, 128, 2, 64) == 1               # few sequences: the tiled kernel
     assert lib.nvh_prefill_varlen_pv16(*pv, p, 4096, None) == -4                      # scratch too small
     assert b"scratch" in lib.nvh_last_error()
     assert lib.nvh_prefill_varlen_pv16(*pv[:9], 0, *pv[10:], p, 1 << 20, None) == -4  # total_k missing

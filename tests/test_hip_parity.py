@@ -531,6 +531,39 @@ def test_config5_prefill_256x128(ops):
 
 
 @pytest.mark.gpu
+def test_config5_prefill_fp16_pv_in_the_short_kernel(ops):
+    """nvh_prefill_varlen_pv16 on BASELINE config 5's batch (128 x 128, the short-sequence kernel): V is converted to fp16 inside each workgroup and
+    P V runs on the fp16 pipe — inside the 1e-3 bar against the oracle and visibly not the exact form; a (sequence, kv head) pair whose V does not
+    fit fp16 takes the exact form by itself, bit for bit; the default rule picks the fp16 form for bf16 output and the exact one for fp32."""
+    H, KVH, D, S, B = 14, 2, 64, 128, 128
+    gen = torch.Generator().manual_seed(56)
+    T = B * S
+    qkv = torch.randn(T, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+    q, k, v = qkv[:, :H * D].view(T, H, D), qkv[:, H * D:(H + KVH) * D].view(T, KVH, D), qkv[:, (H + KVH) * D:].view(T, KVH, D)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device="cuda")
+    exact = ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, out_dtype=torch.float32, pv_fp16=False)
+    fast = ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, out_dtype=torch.float32, pv_fp16=True)
+    torch.cuda.synchronize()
+    assert 2e-5 < (fast - exact).abs().max().item() <= ATOL
+    cu1 = np.array([0, S], np.int32)
+    for i in (0, 63, 127):
+        sl = slice(i * S, (i + 1) * S)
+        exp = O.prefill_varlen(q[sl].float().cpu().numpy(), k[sl].float().cpu().numpy(), v[sl].float().cpu().numpy(), cu1, cu1)
+        assert np.abs(fast[sl].cpu().numpy() - exp).max() <= ATOL
+    assert torch.equal(ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu), ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, pv_fp16=True))
+    assert torch.equal(ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, out_dtype=torch.float32), exact)
+    v[5 * S + 70, 1, 9] = -7e4                                    # sequence 5, kv head 1: does not fit fp16
+    exact = ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, out_dtype=torch.float32, pv_fp16=False)
+    guarded = ops.flash_attn_varlen_func(q, k, v, S, cu, S, cu, out_dtype=torch.float32, pv_fp16=True)
+    torch.cuda.synchronize()
+    G = H // KVH
+    assert torch.isfinite(guarded).all()
+    assert torch.equal(guarded[5 * S:6 * S, G:], exact[5 * S:6 * S, G:])                       # the flagged pair: exact form
+    assert 0 < (guarded[5 * S:6 * S, :G] - exact[5 * S:6 * S, :G]).abs().max().item() <= ATOL   # its sibling kv head and every other sequence: fp16 form
+    assert 0 < (guarded[6 * S:] - exact[6 * S:]).abs().max().item() <= ATOL
+
+
+@pytest.mark.gpu
 def test_decode_packed_output_matches_row_major():
     """nvh_paged_decode_packed: the fragment-order copy is the row-major bf16 output, element for element (incl. ctx 0 rows)."""
     from nanovllm_hip import ops

@@ -127,10 +127,20 @@ def main():
         if args.variant == "tiled_f16v":
             v = v.to(torch.float16)                              # (converted once, outside the timed loop: what a producer-side conversion would hand over)
         pv = None if args.variant or args.waves else {"auto": None, "fp16": True, "exact": False}[args.pv]
-        us = time_loop(lambda l: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu, kernel=args.variant, short_waves=args.waves, pv_fp16=pv), 1, args.iters, args.warmup)
+        call = lambda l=0: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu, kernel=args.variant, short_waves=args.waves, pv_fp16=pv)
+        if args.graph:                                           # 8 calls per replayed graph: no host time between the launches
+            call(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(8):
+                    call()
+            us = time_loop(lambda l: g.replay(), 1, args.iters, args.warmup) / 8
+        else:
+            us = time_loop(call, 1, args.iters, args.warmup)
         flops = b * 4 * d * h * s * (s + 1) / 2
-        form = args.variant or ("fp16 P V (guarded, conversion inside the call)" if pv is True or (pv is None and not args.waves and s >= ops.PV16_MIN_KEYS) else "bf16 hi + lo")
-        print(json.dumps({"mode": "prefill", "batch": b, "seq": s, "shape": [h, kvh, d], "form": form, "us_per_call": round(us, 1),
+        short = d == 64 and 64 < s <= 128 and b * kvh >= 128
+        form = args.variant or ("fp16 P V (guarded, conversion inside the call)" if pv is True or (pv is None and not args.waves and (s >= ops.PV16_MIN_KEYS or short)) else "bf16 hi + lo")
+        print(json.dumps({"mode": "prefill", "graph": args.graph, "batch": b, "seq": s, "shape": [h, kvh, d], "form": form, "us_per_call": round(us, 1),
                           "TFLOPs": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}))
 
 
