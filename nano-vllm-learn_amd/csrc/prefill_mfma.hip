@@ -341,13 +341,20 @@ __device__ __forceinline__ bool prefill_varlen_body(const PrefillArgs& a, unsign
             for (int qs = 0; qs < QT; ++qs) {
                 if (need_mask) {
                     // element (tt, r) of this lane is key kv0 + 16 tt + 4 lg + r; it is visible iff key <= min(q_pos, sk - 1), i.e. iff the
-                    // CONSTANT 16 tt + r is <= a per-lane limit: one compare against an inline constant + one select per element
+                    // CONSTANT 16 tt + r is <= a per-lane limit: one compare against an inline constant + one select per element — and only
+                    // in the 16-key groups that reach past what the sub-tile's FIRST row may see (wave-uniform test): the groups below the
+                    // diagonal block of a diagonal tile are visible to every row
                     const int q_pos = my_q[qs] + shift;                          // last key this lane's query may see
                     const int limit = (q_pos < sk - 1 ? q_pos : sk - 1) - kv0 - 4 * lg;
+                    const int first_row_key = wave_first_key + 16 * qs;
+                    const int all_see = (first_row_key < sk - 1 ? first_row_key : sk - 1) - kv0;      // keys kv0 .. kv0 + all_see: no mask needed
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt)
+                    for (int tt = 0; tt < NT; ++tt) {
+                        if (16 * tt + 15 > all_see) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sT[qs][tt][r] = (16 * tt + r <= limit) ? sT[qs][tt][r] : -INFINITY;
+                            for (int r = 0; r < 4; ++r) sT[qs][tt][r] = (16 * tt + r <= limit) ? sT[qs][tt][r] : -INFINITY;
+                        }
+                    }
                 }
                 float mx = max3(sT[qs][0][0], sT[qs][0][1], sT[qs][0][2]);
                 mx = max3(mx, sT[qs][0][3], sT[qs][1][0]);
@@ -688,11 +695,12 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
             // touches are dead, and on a sub-tile's diagonal tile mask + max + exp2 of a dead group cost as much as those of a live one.
             const bool masked = kv0 + BN - 1 > q0 + shift || kv0 + BN > sk;      // wave-uniform: the tile reaches the diagonal or the end
             const int limit = (q_pos < sk - 1 ? q_pos : sk - 1) - kv0 - 4 * lg;  // see the tiled kernel: constant <= per-lane limit
+            const int all_see = (q0 + shift < sk - 1 ? q0 + shift : sk - 1) - kv0;   // keys every row of the sub-tile sees (wave-uniform)
             float mx = -INFINITY;
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 if (tt < n_tt) {
-                    if (masked) {
+                    if (masked && 16 * tt + 15 > all_see) {                      // (groups below the sub-tile's diagonal block are visible to every row)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sT[tt][r] = (16 * tt + r <= limit) ? sT[tt][r] : -INFINITY;
                     }
@@ -874,7 +882,11 @@ int launch_d(const PrefillArgs& a, hipStream_t stream) {
 #ifndef NVH_PREFILL_QT2_FROM
 #define NVH_PREFILL_QT2_FROM 2048            // D = 64: two 16-row sub-tiles per wave from this many query rows on (A/B builds change it)
 #endif
-    const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= NVH_PREFILL_QT2_FROM;
+#ifndef NVH_PREFILL_QT2_FROM_PV16
+#define NVH_PREFILL_QT2_FROM_PV16 512        // ... in the fp16 P V form: its two-sub-tile body fits 128 registers = 4 waves per SIMD (same-box A/B against 2048:
+                                             // S = 512 42.5 -> 40.5 us, S = 1024 62.8 -> 58.8, S = 1536 77.8 -> 74.0; profiles/r03_prefill_qt2_pv16_ab.txt)
+#endif
+    const bool two = D == 128 ? a.max_seqlen_q > 128 : a.max_seqlen_q >= (a.v16 ? NVH_PREFILL_QT2_FROM_PV16 : NVH_PREFILL_QT2_FROM);
     return two ? launch_q<D, 2>(a, stream) : launch_q<D, 1>(a, stream);
 }
 

@@ -181,7 +181,7 @@ def decode_step(q, k_new, v_new, k_cache, v_cache, slot_mapping, cache_seqlens, 
 
 
 # --------------------------------------------------------------------------------------- prefill
-PV16_MIN_KEYS = 1024      # fp16 P V (nvh_prefill_varlen_pv16) by default from this many keys per sequence on: below, the conversion launch costs what it saves
+PV16_MIN_KEYS = 512       # fp16 P V (nvh_prefill_varlen_pv16) by default from this many keys per sequence on (40.5 vs 42.0 us at 32 x 512; below, the conversion launch costs what it saves)
 
 
 def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu_seqlens_k, softmax_scale=None,
