@@ -25,7 +25,7 @@ class Attention(nn.Module):
         self.num_kv_heads = num_kv_heads
         self.block_size = block_size
         self.fused_decode = fused_decode        # one C-ABI call for store + attend on the decode step
-        # prefill P V on the fp16 matrix pipe (ops.flash_attn_varlen_func pv_fp16): None = the library's rule (bf16 output, packed rows, >= 1024 keys per sequence;
+        # prefill P V on the fp16 matrix pipe (ops.flash_attn_varlen_func pv_fp16): None = the library's rule (bf16 output, packed rows, >= 512 keys per sequence or config 5's short batches;
         # range-guarded, falls back by itself), False = never (P as bf16 hi + lo, 6e-6 instead of <= 2^-12 * max|v|), True = at every length
         self.prefill_pv_fp16 = prefill_pv_fp16
         self.k_cache = self.v_cache = torch.tensor([])

@@ -860,7 +860,7 @@ def test_prefill_pv16_golden_and_range_guard(ops, golden, name):
         exact = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=False)
         fast = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=True)
         assert 2e-5 < (fast - exact).abs().max().item() <= ATOL
-        auto16 = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul)                # default rule: bf16 output, >= 1024 keys -> the fp16 form
+        auto16 = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul)                # default rule: bf16 output, >= 512 keys -> the fp16 form
         assert torch.equal(auto16, ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, pv_fp16=True))
         vl[S // 2, KVH - 1, 3] = 1e5                                                   # does not fit fp16: the flag must send every workgroup of sequence 0 to hi + lo
         exact = ops.flash_attn_varlen_func(ql, kl, vl, S, cul, S, cul, out_dtype=torch.float32, pv_fp16=False)
@@ -885,7 +885,7 @@ def test_prefill_pv16_golden_and_range_guard(ops, golden, name):
 
 @pytest.mark.gpu
 def test_attention_module_fp16_pv_prefill_rule():
-    """Attention(prefill_pv_fp16=None, the default): prefill of sequences with >= 1024 keys runs P V on the fp16 pipe (range-guarded); shorter batches
+    """Attention(prefill_pv_fp16=None, the default): prefill of sequences with >= 512 keys runs P V on the fp16 pipe (range-guarded); shorter batches
     keep the hi + lo form; prefill_pv_fp16=False never does.  Against the oracle at the 1e-3 bar (N(0,1) inputs), and against each other."""
     from nanovllm_hip import reset_context, set_context
     from nanovllm_hip.layers.attention_hip import Attention
