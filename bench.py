@@ -190,14 +190,14 @@ def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6, pv_fp16=None):
     torch.cuda.synchronize()
     # the calls of one pass over the buffers are captured into ONE HIP graph and replayed: at 20 us per call an eager loop measures the host
     # (ctypes + allocator), not the launch; the events bracket the replays on the launching stream
-    outs = []
+    # (the output tensor is dropped after each call, so the captured calls reuse one output block of the graph's pool — as the eager allocator does)
     cold, warm = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
     with torch.cuda.graph(cold):
         for x in qkvs:
-            outs.append(call(x))
+            call(x)
     with torch.cuda.graph(warm):
         for _ in qkvs:
-            outs.append(call(qkvs[0]))
+            call(qkvs[0])
     start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     cold.replay()
     torch.cuda.synchronize()
@@ -217,7 +217,7 @@ def prefill_leg(cfg, tp, batch, seq, buffers=8, iters=6, pv_fp16=None):
     end.record()
     torch.cuda.synchronize()
     us_warm = start.elapsed_time(end) * 1e3 / (iters * buffers)
-    del cold, warm, outs
+    del cold, warm
     flops = batch * 4 * d * h * seq * (seq + 1) / 2                    # QK^T + PV over the causal triangle incl. the diagonal
     nbytes = t * (2 * h + 2 * kvh) * d * 2                              # q in, o out, k and v in
     t_hbm, t_mfma = nbytes / (HBM_PEAK_GBPS * 1e3), flops / (MFMA_PEAK_TFLOPS * 1e6)     # us at the two peaks
