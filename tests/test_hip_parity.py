@@ -531,6 +531,38 @@ def test_config5_prefill_256x128(ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("pv_fp16", [False, True])
+def test_prefill_full_size_properties(ops, pv_fp16):
+    """Size-independent properties at BASELINE config 2's prefill batch (16 sequences x 1024 tokens, 14/2/64), for the exact and the fp16 P V form:
+    (1) linearity in V — doubling V doubles the output bit for bit (a power of two commutes with every rounding of the chain, the fp16 conversion
+    included); (2) sequences are independent — a batch with its sequences in another order gives the same rows; (3) causality — rewriting q / k / v
+    from position t on leaves the rows before t untouched, bit for bit; (4) a constant V comes back as that constant."""
+    H, KVH, D, S, B = 14, 2, 64, 1024, 16
+    gen = torch.Generator().manual_seed(77)
+    T = B * S
+    qkv = torch.randn(T, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+    split = lambda x: (x[:, :H * D].view(-1, H, D), x[:, H * D:(H + KVH) * D].view(-1, KVH, D), x[:, (H + KVH) * D:].view(-1, KVH, D))
+    q, k, v = split(qkv)
+    cu = torch.arange(0, T + 1, S, dtype=torch.int32, device="cuda")
+    run = lambda q_, k_, v_: ops.flash_attn_varlen_func(q_, k_, v_, S, cu, S, cu, out_dtype=torch.float32, pv_fp16=pv_fp16)
+    base = run(q, k, v)
+    assert torch.isfinite(base).all()
+    assert torch.equal(run(q, k, (v.float() * 2).bfloat16()), base * 2)                                    # (1)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    rows = (perm[:, None] * S + torch.arange(S)[None, :]).reshape(-1).cuda()
+    q2, k2, v2 = split(qkv[rows].contiguous())
+    assert torch.equal(run(q2, k2, v2), base[rows])                                                        # (2)
+    t = 700
+    qkv3 = qkv.clone()
+    tail = (torch.arange(B)[:, None] * S + torch.arange(t, S)[None, :]).reshape(-1).cuda()
+    qkv3[tail] = torch.randn(tail.numel(), qkv.shape[1], generator=torch.Generator().manual_seed(9)).bfloat16().cuda()
+    head_rows = (torch.arange(B)[:, None] * S + torch.arange(t)[None, :]).reshape(-1).cuda()
+    assert torch.equal(run(*split(qkv3))[head_rows], base[head_rows])                                      # (3)
+    vc = torch.full_like(v, 0.375)
+    assert (run(q, k, vc) - 0.375).abs().max().item() <= ATOL                                              # (4)
+
+
+@pytest.mark.gpu
 def test_config5_prefill_fp16_pv_in_the_short_kernel(ops):
     """nvh_prefill_varlen_pv16 on BASELINE config 5's batch (128 x 128, the short-sequence kernel): V is converted to fp16 inside each workgroup and
     P V runs on the fp16 pipe — inside the 1e-3 bar against the oracle and visibly not the exact form; a (sequence, kv head) pair whose V does not
