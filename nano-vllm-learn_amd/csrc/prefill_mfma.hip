@@ -540,8 +540,15 @@ void prefill_varlen_kernel(const PrefillArgs a) {
 // the staging one, the next task's Q rows are in flight while the current task computes, every HBM byte is read once.
 // Task t = (head g, sub-tile); the sub-tile index is rotated by g so that the causal triangle's light and heavy sub-tiles are
 // spread evenly over the waves.
+#ifndef NVH_SHORT_SPLIT
+#define NVH_SHORT_SPLIT 1                    // A/B builds: workgroups per (sequence, kv head) pair (the tasks dealt round-robin to them)
+#endif
+#ifndef NVH_SHORT_WAVES_PER_EU
+#define NVH_SHORT_WAVES_PER_EU 1             // A/B builds: occupancy target of the 8-wave instantiation (register cap)
+#endif
 template <int D, int NKT, int NW>
-__global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArgs a) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(D == 64 && NW == 8 ? NVH_SHORT_WAVES_PER_EU : 1)))
+void prefill_short_kernel(const PrefillArgs a) {
     constexpr int ROWB = D * 2, LPT = D / 8, TPI = 64 / LPT, IMG = BN * ROWB, NI = IMG / 1024;
     constexpr int STEPS = D / 32, DT = D / 16, NT = BN / 16;
     static_assert((NKT - 1) * 2 * IMG + IMG + 48 * ROWB < 65536, "transposed V reads address tiles through the 16-bit ds offset");
@@ -604,7 +611,8 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
         }
     };
     bf16x8 qf[STEPS];
-    int t = wave;
+    const int t_step = NW * (int)gridDim.z;          // (gridDim.z workgroups share the pair's tasks: A/B builds; 1 in the shipped launch)
+    int t = wave * (int)gridDim.z + (int)blockIdx.z;
     if (t < n_tasks) load_q(t, qf);
     SK_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                             // this wave's share of the images (and its first Q)
@@ -647,9 +655,9 @@ __global__ __launch_bounds__(NW * 64) void prefill_short_kernel(const PrefillArg
 
     auto run_tasks = [&](auto f16c) {
     constexpr bool F16 = decltype(f16c)::value;
-    for (; t < n_tasks; t += NW) {
+    for (; t < n_tasks; t += t_step) {
         bf16x8 qn[STEPS];
-        if (t + NW < n_tasks) load_q(t + NW, qn);                                // in flight while this task computes
+        if (t + t_step < n_tasks) load_q(t + t_step, qn);                        // in flight while this task computes
         int head, q0;
         task_of(t, head, q0);
         const int my_q = q0 + lq;
@@ -858,11 +866,15 @@ int launch_short(const PrefillArgs& a, hipStream_t stream, bool& taken) {
     if (mode == 0 || a.block_tables || a.max_seqlen_k > max_keys || a.max_seqlen_q > a.max_seqlen_k) return 0;
     if (mode != 2 && a.batch * a.kvh < 128) return 0;            // few sequences: the tiled kernel spreads heads and q-tiles over the CUs
     taken = true;
-    dim3 grid(a.kvh, a.batch);
+    dim3 grid(a.kvh, a.batch, NVH_SHORT_SPLIT);
     // a wave's tile is a long dependent chain (QK -> max -> exp2 -> hi/lo -> PV): four waves per SIMD to fill it where the registers allow
     // (measured, Qwen2-0.5B heads, S = 128: 256 workgroups 22.7 us with 16 waves against 25.2 with 8; 512 workgroups, two per CU,
     // 37.4 us with 8 against 41.9 with 16; the tiled kernel 28.3 / 56)
+#ifdef NVH_SHORT_FORCE_WAVES                  // A/B builds
+    const int waves = a.short_waves ? a.short_waves : NVH_SHORT_FORCE_WAVES;
+#else
     const int waves = a.short_waves ? a.short_waves : (a.batch * a.kvh >= 384 ? 8 : 16);
+#endif
     if constexpr (D == 64) {
         if (waves == 16) {
             hipLaunchKernelGGL((prefill_short_kernel<D, 2, 16>), grid, dim3(1024), 0, stream, a);
