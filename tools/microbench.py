@@ -36,7 +36,9 @@ def make_decode(args, dev):
     need = (ctxs + bs - 1) // bs
     width = args.width or int(need.max())
     nb = int(need.sum()) + 1
-    caches = [torch.randn(2, nb, bs, kvh, d, device=dev, dtype=torch.bfloat16) for _ in range(args.layers)]
+    n_caches = args.caches or args.layers                   # (--caches n < layers: the calls cycle over n caches — K/V re-read from the Infinity Cache)
+    caches = [torch.randn(2, nb, bs, kvh, d, device=dev, dtype=torch.bfloat16) for _ in range(n_caches)]
+    caches = [caches[l % n_caches] for l in range(args.layers)]
     bt = np.zeros((b, width), np.int32)
     ids = iter(rng.permutation(nb).tolist())
     for i in range(b):
@@ -73,6 +75,7 @@ def main():
     ap.add_argument("--block-size", type=int, default=256)
     ap.add_argument("--width", type=int, default=0, help="block-table width (0 = tight; 16 = graph-replay shape)")
     ap.add_argument("--layers", type=int, default=24)
+    ap.add_argument("--caches", type=int, default=0, help="decode: distinct K/V caches the `layers` calls cycle over (0 = one per call)")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--graph", action="store_true", help="time a HIP graph of `layers` back-to-back launches")
