@@ -302,6 +302,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="no HIP graph (debug)")
     ap.add_argument("--graph-steps", type=int, default=0, help="A/B: decode steps captured per replayed graph (0 = the session's default)")
+    ap.add_argument("--kv-ahead", default=None, choices=["o_k+gu_v", "o_v+gu_k", "o_k", "gu_k"],
+                    help="A/B: the o_proj / gate_up launches of a layer touch the NEXT layer's K / V cache regions (Infinity-Cache prefetch experiment, DESIGN.md 12.1)")
     ap.add_argument("--no-prefetch", action="store_true", help="A/B: the qkv / down launches do not prefetch the next small projection's weights")
     ap.add_argument("--qkv-attend", default=None, choices=["two_launches", "one_launch", "two_launches_kv_prefetch", "auto"],
                     help="A/B: how the qkv projection + decode attention front of a layer runs (nvh_qkv_rope_attend_variant)")
@@ -343,8 +345,10 @@ def main():
     if args.graph_steps > 0:
         from nanovllm_hip.engine import model_runner as _mr
         _mr.DecodeSession.MULTI = args.graph_steps
+    from nanovllm_hip.models import qwen as _qwen
+    if args.kv_ahead:
+        _qwen.KV_AHEAD = args.kv_ahead
     if args.no_prefetch:
-        from nanovllm_hip.models import qwen as _qwen
         _qwen.PREFETCH_WEIGHTS = False
     if args.qkv_attend:
         from nanovllm_hip.models import qwen as _qwen

@@ -517,7 +517,10 @@ static int linear_args(LinearArgs& a, const nvh_linear_desc* d, int dtype) {
     // few dozen workgroups); 8.7 and 17.4 MB ranges measured +-0 and +1.3 % on the decode step (the prefetching workgroups outlive the launch)
     a.pf_ptr = nullptr; a.pf_bytes = 0;
     a.pf_kv = {};
-    if (d->prefetch && d->prefetch_bytes >= 256 && d->prefetch_bytes <= ((size_t)4 << 20)) {
+#ifndef NVH_PF_MAX_MB
+#define NVH_PF_MAX_MB 4                      // (A/B builds lift it)
+#endif
+    if (d->prefetch && d->prefetch_bytes >= 256 && d->prefetch_bytes <= ((size_t)NVH_PF_MAX_MB << 20)) {
         const uintptr_t p0 = ((uintptr_t)d->prefetch + 127) & ~(uintptr_t)127, p1 = ((uintptr_t)d->prefetch + d->prefetch_bytes) & ~(uintptr_t)127;
         if (p1 > p0) { a.pf_ptr = (const void*)p0; a.pf_bytes = (int64_t)(p1 - p0); }
     }

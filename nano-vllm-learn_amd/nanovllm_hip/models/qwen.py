@@ -276,6 +276,8 @@ class QwenDecoderLayer(nn.Module):
 
 
 FUSED_DECODE = True          # tests flip this to compare the fused decode layer with the plain one
+KV_AHEAD = None              # A/B runs only (bench.py --kv-ahead): "o_k+gu_v" / "o_v+gu_k" / "o_k" — the o_proj / gate_up launches of layer i touch layer i + 1's whole
+                             # K / V cache regions (plain pointer prefetch: only meaningful when the cache holds little more than the live blocks, as in bench.py)
 PREFETCH_WEIGHTS = True      # qkv / down launches pull the NEXT small projection's weights into the caches on their idle CUs (A/B runs flip it)
 QKV_ATTEND_MODE = "two_launches"   # how nvh_qkv_rope_attend runs the front of a decode layer (ops.QKV_ATTEND_MODES; A/B runs change it)
 KV_PREFETCH_PASSES = 1             # mode "two_launches_kv_prefetch": first passes of every attention workgroup the qkv launch touches
@@ -402,6 +404,10 @@ class QwenForCausalLM(nn.Module):
             pf_in_qkv = a.o_proj.weight if PREFETCH_WEIGHTS else None
             pf_in_dn = fw["qkv"][i + 1] if PREFETCH_WEIGHTS and nxt[i] is not None else None
             pf_in_o = pf_in_gu = None
+            if KV_AHEAD and nxt[i] is not None:
+                nk, nv = nxt[i].self_attn.attn.k_cache, nxt[i].self_attn.attn.v_cache
+                if nk.numel():
+                    pf_in_o, pf_in_gu = {"o_k+gu_v": (nk, nv), "o_v+gu_k": (nv, nk), "o_k": (nk, None), "gu_k": (None, nk)}[KV_AHEAD]
             if i == 0:                                                    # layer 0 reads the embedding rows as they are, or packed
                 x, xrows = (residual, None) if packed0 is None else (packed0, m)
             else:
