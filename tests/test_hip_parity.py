@@ -531,6 +531,25 @@ def test_config5_prefill_256x128(ops):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("H,KVH,D", [(14, 2, 64), (16, 8, 128), (7, 1, 128)])
+def test_prefill_pv16_ragged_batches_vs_oracle(ops, H, KVH, D):
+    """The fp16 P V form on ragged batches whose longest sequence takes the two-sub-tile shape (lengths around the 64-row flag groups, the 128-row
+    workgroup tiles and the 64-key tiles, single-token sequences in between): every row against the oracle at the 1e-3 bar, fp32 output."""
+    rng = np.random.default_rng(H * 100 + D)
+    for lens in ([513, 1, 700, 64, 1025], [1536, 127, 129, 1], [640, 639, 641, 2, 63, 65, 1300]):
+        T = sum(lens)
+        gen = torch.Generator().manual_seed(T + D)
+        qkv = torch.randn(T, (H + 2 * KVH) * D, generator=gen).bfloat16().cuda()
+        q, k, v = qkv[:, :H * D].view(T, H, D), qkv[:, H * D:(H + KVH) * D].view(T, KVH, D), qkv[:, (H + KVH) * D:].view(T, KVH, D)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        got = ops.flash_attn_varlen_func(q, k, v, max(lens), dev_i32(cu), max(lens), dev_i32(cu), out_dtype=torch.float32, pv_fp16=True)
+        torch.cuda.synchronize()
+        exp = O.prefill_varlen(q.float().cpu().numpy(), k.float().cpu().numpy(), v.float().cpu().numpy(), cu, cu)
+        err = np.abs(got.cpu().numpy() - exp).max()
+        assert err <= ATOL, f"{H}/{KVH}/{D} lens {lens}: max abs err {err:.3e}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pv_fp16", [False, True])
 def test_prefill_full_size_properties(ops, pv_fp16):
     """Size-independent properties at BASELINE config 2's prefill batch (16 sequences x 1024 tokens, 14/2/64), for the exact and the fp16 P V form:
