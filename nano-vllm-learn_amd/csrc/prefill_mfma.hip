@@ -139,7 +139,11 @@ __device__ __forceinline__ void prefill_tile_of_block(const PrefillArgs& a, int&
         if ((units & 7) == 0 && (total & 7) == 0) {
             const int lin = (int)blockIdx.x + (int)gridDim.x * ((int)blockIdx.y + (int)gridDim.y * (int)blockIdx.z);
             const int xcd = lin & 7, idx = lin >> 3, per = units >> 3;
+#ifdef NVH_PREFILL_PAIR_MAJOR                 // A/B builds: one pair after the other on an XCD (its K/V alone in the L2) instead of all of the XCD's pairs per q-tile rank
+            const int g_in = idx % G, r = idx / G, zs = (int)gridDim.z, u = xcd + 8 * (r / zs), z = r % zs;
+#else
             const int g_in = idx % G, r = idx / G, u = xcd + 8 * (r % per), z = r / per;
+#endif
             b = u / a.kvh;
             head = (u - b * a.kvh) * G + g_in;
             qt = (int)gridDim.z - 1 - z;
