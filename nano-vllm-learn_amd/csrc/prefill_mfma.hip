@@ -23,6 +23,10 @@
 //                   (hardware transpose of a 4-key x 16-dim block) from row-major V.  P enters as hi + lo bf16
 //                   halves (two MFMAs per tile) so it keeps ~16 mantissa bits (1e-3 parity bar at |o| ~ 3).
 //                   C layout: lane l, reg r holds O^T[dim 16t+4(l>>4)+r][query l&15] -> 4 contiguous dims per lane.
+// Two forms of P V (template parameter PV of the kernel): the exact one above (nvh_prefill_varlen) and, for nvh_prefill_varlen_pv16, P rounded to fp16
+// against an fp16 copy of V — ONE v_mfma_f32_16x16x32_f16 per operand pair, a third fewer vector instructions per tile (the loop is bound by vector
+// issue) — behind a range guard: the conversion launch flags every 64 rows of V that do not fit fp16 and a flagged sequence runs the exact body.
+// Workgroup order: XCD-aware (the heads x q-tiles that stream one (sequence, kv head)'s K/V share one XCD's L2), heaviest q-tiles first.
 // Causal structure: a workgroup only walks the key tiles its rows can see; a wave skips the MFMA work of tiles that lie
 // entirely above its own 16 rows' diagonal (it still takes part in the staging and the barriers).
 // Algorithmic flops per launch: sum_seq 4*D*H*(causal pairs); bytes: Tq*H*D*2*2 + Tk*KVH*D*2*2.
