@@ -550,6 +550,36 @@ def test_prefill_pv16_ragged_batches_vs_oracle(ops, H, KVH, D):
 
 
 @pytest.mark.gpu
+def test_prefill_pv16_random_geometries_against_the_exact_form(ops):
+    """24 random batches (head shapes of the three models, 1-9 sequences of 1-2600 tokens, strided q / k / v views, an out-of-range V value in a random
+    sequence of every third batch): the fp16 form stays within the bar of the exact one everywhere, and the flagged sequence's rows equal it bit for bit."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        H, KVH, D = [(14, 2, 64), (16, 8, 128), (7, 1, 128), (28, 4, 128)][case % 4]
+        n = int(rng.integers(1, 10))
+        lens = [int(x) for x in rng.integers(1, 2600, n)]
+        lens[int(rng.integers(0, n))] = int(rng.integers(512, 2600))              # the batch takes the tiled kernel's long shapes
+        T = sum(lens)
+        gen = torch.Generator().manual_seed(1000 + case)
+        qkv = torch.randn(T, (H + 2 * KVH) * D + 16, generator=gen).bfloat16().cuda()     # (+16: rows are not densely packed)
+        q, k, v = qkv[:, :H * D].view(T, H, D), qkv[:, H * D:(H + KVH) * D].view(T, KVH, D), qkv[:, (H + KVH) * D:(H + 2 * KVH) * D].view(T, KVH, D)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        bad = None
+        if case % 3 == 0:
+            bad = int(rng.integers(0, n))
+            v[int(cu[bad]) + int(rng.integers(0, lens[bad])), int(rng.integers(0, KVH)), int(rng.integers(0, D))] = 9e4
+        exact = ops.flash_attn_varlen_func(q, k, v, max(lens), dev_i32(cu), max(lens), dev_i32(cu), out_dtype=torch.float32, pv_fp16=False)
+        fast = ops.flash_attn_varlen_func(q, k, v, max(lens), dev_i32(cu), max(lens), dev_i32(cu), out_dtype=torch.float32, pv_fp16=True)
+        torch.cuda.synchronize()
+        for i in range(n):
+            a, b = fast[cu[i]:cu[i + 1]], exact[cu[i]:cu[i + 1]]
+            if i == bad:
+                assert torch.equal(a, b), f"case {case}: flagged sequence {i} differs from the exact form"
+            else:
+                assert (a - b).abs().max().item() <= ATOL, f"case {case} ({H}/{KVH}/{D}, lens {lens}): sequence {i}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("pv_fp16", [False, True])
 def test_prefill_full_size_properties(ops, pv_fp16):
     """Size-independent properties at BASELINE config 2's prefill batch (16 sequences x 1024 tokens, 14/2/64), for the exact and the fp16 P V form:
