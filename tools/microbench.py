@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="time a HIP graph of `layers` back-to-back launches")
     ap.add_argument("--fused", action="store_true", help="decode: time nvh_decode_step (store + attend)")
     ap.add_argument("--seq", type=int, default=1024, help="prefill: sequence length")
+    ap.add_argument("--paged", action="store_true", help="prefill: K / V through the paged cache and a shuffled block table (prefix-cached / chunked prefill)")
+    ap.add_argument("--q-len", type=int, default=0, help="prefill --paged: new tokens per sequence (the last q-len of --seq; 0 = all)")
     ap.add_argument("--pv", default="auto", choices=["auto", "fp16", "exact"], help="prefill: P V form (ops.flash_attn_varlen_func pv_fp16 = None / True / False)")
     ap.add_argument("--variant", default=None, help="decode: chunked | chunked_p64 | chunked_p128 | chunked_p256 | split_mfma | split_valu (nvh_paged_decode_variant); prefill: auto | tiled | short | tiled_f16v")
     ap.add_argument("--waves", type=int, default=0, help="decode (chunked, D=64): 4 or 8 waves; prefill short kernel: 8 or 16")
@@ -129,6 +131,28 @@ def main():
         cu = torch.arange(0, t + 1, s, dtype=torch.int32, device=dev)
         if args.variant == "tiled_f16v":
             v = v.to(torch.float16)                              # (converted once, outside the timed loop: what a producer-side conversion would hand over)
+        if args.paged:
+            # prefix-cached / chunked form (attention.py:90-96 with block_table): K / V of every sequence live in the paged cache behind a shuffled block
+            # table; q holds the LAST --q-len tokens of each sequence (0 = all of them), bottom-right aligned causal mask
+            bs = args.block_size
+            nblk = (s + bs - 1) // bs
+            perm = torch.randperm(b * nblk, device=dev).int().view(b, nblk)
+            kc = torch.zeros(b * nblk, bs, kvh, d, device=dev, dtype=torch.bfloat16)
+            vc = torch.zeros_like(kc)
+            for i in range(b):
+                for j in range(nblk):
+                    n = min(bs, s - j * bs)
+                    kc[perm[i, j], :n] = k[i * s + j * bs: i * s + j * bs + n]
+                    vc[perm[i, j], :n] = v[i * s + j * bs: i * s + j * bs + n]
+            ql = args.q_len or s
+            rows = (torch.arange(b, device=dev)[:, None] * s + torch.arange(s - ql, s, device=dev)[None, :]).reshape(-1)
+            qp = qkv[rows][:, :h * d].contiguous().view(b * ql, h, d)
+            cuq = torch.arange(0, b * ql + 1, ql, dtype=torch.int32, device=dev)
+            us = time_loop(lambda l: ops.flash_attn_varlen_func(qp, kc, vc, ql, cuq, s, cu, block_table=perm), 1, args.iters, args.warmup)
+            flops = b * 4 * d * h * (ql * (s - ql) + ql * (ql + 1) / 2)
+            print(json.dumps({"mode": "prefill_paged", "batch": b, "q_len": ql, "k_len": s, "shape": [h, kvh, d], "us_per_call": round(us, 1),
+                              "TFLOPs": round(flops / us / 1e6, 1), "frac_of_2.5PF": round(flops / us / 1e6 / 2500, 4)}))
+            return
         pv = None if args.variant or args.waves else {"auto": None, "fp16": True, "exact": False}[args.pv]
         call = lambda l=0: ops.flash_attn_varlen_func(q, k, v, s, cu, s, cu, kernel=args.variant, short_waves=args.waves, pv_fp16=pv)
         if args.graph:                                           # 8 calls per replayed graph: no host time between the launches
